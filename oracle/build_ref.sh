@@ -1,0 +1,87 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE ONLY -- builds the *reference's own* kernel sources, where they lie under
+# /root/reference, into oracle/_ref/ (git-ignored, but shipped to the GPU box with the snapshot).
+#
+# What is built and why it is legitimate:
+#   * Only reference .c files are compiled, straight from /root/reference (nothing is copied into
+#     the repo).  No stand-in is written for anything the image lacks: the reference's 9 NASM files
+#     cannot be assembled here (no nasm/yasm), so every object that needs one of their 36 symbols on
+#     a path we drive is simply NOT used.  Unused functions that mention a NASM symbol are dropped by
+#     --gc-sections (roots = the exported list below), so the library has no unresolved symbols.
+#   * libsvtref_kernels.so : leaf kernels of the ME path (both asm_type rows):
+#       C_DEFAULT/EbComputeSAD_C.c, ASM_SSE2/EbMeSadCalculation_Intrinsic_SSE2.c,
+#       ASM_SSE4_1/EbComputeSAD_Intrinsic_SSE4_1.c, ASM_AVX2/EbComputeSAD_Intrinsic_AVX2.c,
+#       ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c (wrapped SSD),
+#       ASM_SSSE3/EbAvcStyleMcp_Intrinsic_SSSE3.c (4-tap half-pel filters),
+#       ASM_SSE2/EbCombinedAveragingSAD_Intrinsic_SSE2.c, ASM_AVX2/EbCombinedAveragingSAD_Intrinsic_AVX2.c
+#   The repo's oracle (oracle/*.c) is validated against these in tests/test_oracle_vs_ref.py, and
+#   tests/golden/ fixtures are generated from them by tests/golden/make_golden.py.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+REF="${SVT_REFERENCE_ROOT:-/root/reference}"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/Source/Lib/Codec" ]; then
+  echo "build_ref: $REF not present (GPU box) - using prebuilt oracle/_ref if any" >&2
+  exit 0
+fi
+mkdir -p "$OUT/obj"
+S="$REF/Source"
+INC="-I$S/API -I$S/Lib/Codec -I$S/Lib/C_DEFAULT -I$S/Lib/ASM_SSE2 -I$S/Lib/ASM_SSSE3 -I$S/Lib/ASM_SSE4_1 -I$S/Lib/ASM_AVX2"
+CFLAGS="-O2 -std=c99 -w -mavx2 -fPIC -ffunction-sections -fdata-sections"
+FILES=(
+  Lib/C_DEFAULT/EbComputeSAD_C.c
+  Lib/ASM_SSE2/EbMeSadCalculation_Intrinsic_SSE2.c
+  Lib/ASM_SSE2/EbCombinedAveragingSAD_Intrinsic_SSE2.c
+  Lib/ASM_SSE4_1/EbComputeSAD_Intrinsic_SSE4_1.c
+  Lib/ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c
+  Lib/ASM_SSSE3/EbAvcStyleMcp_Intrinsic_SSSE3.c
+  Lib/ASM_AVX2/EbComputeSAD_Intrinsic_AVX2.c
+  Lib/ASM_AVX2/EbCombinedAveragingSAD_Intrinsic_AVX2.c
+)
+OBJS=()
+for f in "${FILES[@]}"; do
+  o="$OUT/obj/$(basename "$f" .c).o"
+  if [ ! -f "$o" ] || [ "$S/$f" -nt "$o" ]; then
+    gcc $CFLAGS $INC -c "$S/$f" -o "$o"
+  fi
+  OBJS+=("$o")
+done
+# our own drivers that replay the call sequence of the reference's *static* L2 functions over the
+# reference kernels (they contain no reference code, only calls into it)
+for f in "$HERE"/ref_*_driver.c; do
+  o="$OUT/obj/$(basename "$f" .c).o"
+  gcc -O2 -std=gnu99 -Wall -mavx2 -fPIC -ffunction-sections -c "$f" -o "$o"
+  OBJS+=("$o")
+done
+# exported roots (everything else is local and garbage-collected)
+cat > "$OUT/obj/kernels.map" <<'EOF'
+{
+  global:
+    SadLoopKernel; FastLoop_NxMSadKernel; CombinedAveragingSAD;
+    SadLoopKernel_SSE4_1_INTRIN; SadLoopKernel_SSE4_1_HmeL0_INTRIN;
+    SadLoopKernel_AVX2_INTRIN; SadLoopKernel_AVX2_HmeL0_INTRIN;
+    GetEightHorizontalSearchPointResults_8x8_16x16_PU_SSE41_INTRIN;
+    GetEightHorizontalSearchPointResults_32x32_64x64_PU_SSE41_INTRIN;
+    GetEightHorizontalSearchPointResults_8x8_16x16_PU_AVX2_INTRIN;
+    GetEightHorizontalSearchPointResults_32x32_64x64_PU_AVX2_INTRIN;
+    SadCalculation_8x8_16x16_SSE2_INTRIN; SadCalculation_32x32_64x64_SSE2_INTRIN;
+    InitializeBuffer_32bits_SSE2_INTRIN;
+    ExtSadCalculation_8x8_16x16_SSE4_INTRIN; ExtSadCalculation_32x32_64x64_SSE4_INTRIN;
+    SpatialFullDistortionKernel4x4_SSSE3_INTRIN; SpatialFullDistortionKernel8x8_SSSE3_INTRIN;
+    SpatialFullDistortionKernel16MxN_SSSE3_INTRIN;
+    AvcStyleLumaInterpolationFilterHorizontal_SSSE3_INTRIN;
+    AvcStyleLumaInterpolationFilterVertical_SSSE3_INTRIN;
+    Compute4xMSad_AVX2_INTRIN; Compute8xMSad_AVX2_INTRIN; Compute16xMSad_AVX2_INTRIN;
+    Compute24xMSad_AVX2_INTRIN; Compute32xMSad_AVX2_INTRIN; Compute48xMSad_AVX2_INTRIN;
+    Compute64xMSad_AVX2_INTRIN;
+    CombinedAveraging8xMSAD_AVX2_INTRIN; CombinedAveraging16xMSAD_AVX2_INTRIN;
+    CombinedAveraging24xMSAD_AVX2_INTRIN; CombinedAveraging32xMSAD_AVX2_INTRIN;
+    CombinedAveraging48xMSAD_AVX2_INTRIN; CombinedAveraging64xMSAD_AVX2_INTRIN;
+    CombinedAveraging4xMSAD_SSE2_INTRIN;
+    ref_*;
+  local: *;
+};
+EOF
+gcc -shared -o "$OUT/libsvtref_kernels.so" "${OBJS[@]}" \
+    -Wl,--gc-sections -Wl,--version-script="$OUT/obj/kernels.map" -Wl,-z,defs -lc
+echo "built $OUT/libsvtref_kernels.so"

@@ -1,0 +1,59 @@
+/*
+ * oracle/svt_me_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's (ateme-developers/SVT-AV1-1) motion-estimation hot path,
+ * asm_type = ASM_NON_AVX2 semantics.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may call into this; the product path (svt-av1-1_amd/csrc) never does.
+ *
+ * Pinning: the reference ships no tests / golden vectors for this path, so every
+ * function here is pinned against the reference's own kernels compiled from /root/reference into
+ * oracle/_ref/ (oracle/build_ref.sh) by tests/test_oracle_vs_ref.py, and against tests/golden/
+ * fixtures generated from those kernels (tests/golden/make_golden.py).
+ *
+ * All paths cited are under /root/reference/Source/Lib/.
+ */
+#ifndef SVT_ME_ORACLE_H
+#define SVT_ME_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_SAD_VALUE (128u * 128u * 255u) /* Codec/EbMotionEstimation.h:78 */
+#define ORC_NUM_SQ_PU 85
+
+/* C_DEFAULT/EbComputeSAD_C.c:49-71 (FastLoop_NxMSadKernel) */
+uint32_t orc_nxm_sad(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                     uint32_t height, uint32_t width);
+
+/* C_DEFAULT/EbComputeSAD_C.c:73-119 (SadLoopKernel): exhaustive search, strict '<' in raster order,
+ * bestSad starts at 0xffffff; x/y untouched when nothing beats it. */
+void orc_sad_loop_kernel(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                         uint32_t height, uint32_t width, uint64_t *best_sad, int16_t *x_center,
+                         int16_t *y_center, uint32_t ref_stride_raw, int16_t search_area_width,
+                         int16_t search_area_height);
+
+/* FullPelSearch_LCU (Codec/EbMotionEstimation.c:1504-1551) over one SB and one reference list.
+ *   src        : top-left of the 64x64 source SB inside the padded source plane (stride src_stride)
+ *   ref        : reference sample at search position (0,0), i.e. integer_buffer_ptr + 2 + 2*stride
+ *   best_sad/mv: 85 entries each, ME-buffer order (0: 64x64, 1-4: 32x32, 5-20: 16x16 z-order,
+ *                21-84: 8x8 = 21 + 4*z16 + raster-in-16x16); updated in place with strict '<'.
+ * SADs are the vertically 2:1 subsampled ones, doubled.
+ * MV word = (uint16)(4*(y_origin+ys)) << 16 | (uint16)(4*(x_origin+xs))  (:1389-1391). */
+void orc_fullpel_search_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref, uint32_t ref_stride,
+                             int16_t x_search_area_origin, int16_t y_search_area_origin,
+                             uint32_t search_area_width, uint32_t search_area_height, uint32_t *best_sad,
+                             uint32_t *best_mv);
+
+void orc_init_best(uint32_t *best_sad, uint32_t *best_mv, uint32_t n);
+
+/* n_sb independent searches; desc[i] = {src_offset, ref_offset, x_origin, y_origin, sw, sh} with the
+ * offsets in bytes into the two planes; outputs [n_sb][85], initialised to MAX_SAD_VALUE / 0 first. */
+void orc_fullpel_search_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane,
+                              uint32_t ref_stride, const int32_t *desc, uint32_t n_sb, uint32_t *best_sad,
+                              uint32_t *best_mv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
