@@ -1,0 +1,103 @@
+/*
+ * include/svtav1_hip.h -- C ABI of the MI355X (gfx950) motion-estimation / transform / quantisation
+ * engine for the SVT-AV1 encoder pipeline.
+ *
+ * Plain C, no C++/torch types: this is what the reference's C host code binds.
+ * Every entry point cites the reference interface it replaces; paths are under
+ * Source/Lib/ of ateme-developers/SVT-AV1-1.
+ *
+ * Conventions
+ *   - return value: 0 = EB_ErrorNone; a negative value carries an EbErrorType-compatible code
+ *     (Source/API/EbApi.h:85-100), text via svthip_last_error().  Entry points never fall back to a CPU
+ *     implementation: if the device or the code object is unavailable they fail.
+ *   - `_dev` entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t passed as void*;
+ *     NULL = the context's own stream) without synchronising; the host-pointer forms copy in, run,
+ *     copy out and synchronise, so the caller's buffers are authoritative on return (SURVEY 8b ownership).
+ *   - all planes are 8-bit luma, laid out exactly like EbPictureBufferDesc_t::bufferY: `stride` bytes per
+ *     row, picture origin at (origin_x, origin_y) = the padding (68 / 32 / 16 px).
+ */
+#ifndef SVTAV1_HIP_H
+#define SVTAV1_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVTHIP_OK 0
+#define SVTHIP_ERR_INSUFFICIENT_RESOURCES ((int32_t)0x80001000) /* EB_ErrorInsufficientResources */
+#define SVTHIP_ERR_BAD_PARAMETER ((int32_t)0x80001005)          /* EB_ErrorBadParameter */
+#define SVTHIP_ERR_DEVICE ((int32_t)0x80002000)                 /* no GPU / HIP failure (no CPU fallback) */
+
+#define SVTHIP_NUM_SQ_PU 85          /* MAX_ME_PU_COUNT square part: 64x64, 4x32x32, 16x16x16, 64x8x8 */
+#define SVTHIP_MAX_SAD_VALUE (128u * 128u * 255u) /* Codec/EbMotionEstimation.h:78 */
+
+typedef struct svthip_ctx svthip_ctx;
+
+/* One context per ME/EncDec thread context (MeContext_t / EncDecContext_t): owns a HIP stream and
+ * device scratch; re-entrant across contexts (SURVEY 8b threading).  Created where the reference
+ * builds MeContext_t (Codec/EbMotionEstimationContext.c:28-122). */
+int32_t svthip_create(int32_t device, svthip_ctx **out_ctx);
+void svthip_destroy(svthip_ctx *ctx);
+const char *svthip_last_error(void);
+/* HIP stream of the context (hipStream_t as void*), for callers that order their own copies. */
+void *svthip_stream(svthip_ctx *ctx);
+int32_t svthip_synchronize(svthip_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-pel 85-PU search of a batch of superblocks against one reference list.
+ * Replaces FullPelSearch_LCU + GetEightHorizontalSearchPointResultsAll85PUs + GetSearchPointResults
+ * (Codec/EbMotionEstimation.c:1504-1551, :1369-1499, :1237-1364) and the leaf kernels behind
+ * GetEightHorizontalSearchPointResults_8x8_16x16_funcPtrArray / _32x32_64x64_funcPtrArray
+ * (Codec/EbComputeSAD.h:183-212) and SadCalculation_*_funcPtrArray (Codec/EbMeSadCalculation.h:97-120),
+ * asm_type = ASM_NON_AVX2 semantics, for all SBs of an ME segment in one launch.
+ *
+ * desc[i] (six int32 per SB):
+ *   [0] src_offset : byte offset of the SB's top-left source sample in the source plane
+ *                    (== MeContext_t::sb_src_ptr - bufferY, Codec/EbMotionEstimationProcess.c:514);
+ *                    must be a multiple of 4 (always true for the reference's planes)
+ *   [1] ref_offset : byte offset of search position (0,0) in the reference plane
+ *                    (== integer_buffer_ptr + 2 + 2*stride - bufferY, Codec/EbMotionEstimation.c:1379)
+ *   [2] x_search_area_origin, [3] y_search_area_origin : full-pel, relative to the SB origin (:6725-6726)
+ *   [4] search_area_width, [5] search_area_height      : 1..127 (:6644-6645, after edge clipping :6689-6723)
+ *
+ * best_sad / best_mv : [n_sb][85] in ME-buffer order (p_sb_best_sad/p_sb_best_mv, PU 0 = 64x64, 1-4 = 32x32,
+ *   5-20 = 16x16 z-order, 21-84 = 8x8 as 21 + 4*z16 + raster-in-16x16).  Both arrays are fully
+ *   overwritten: the search starts from MAX_SAD_VALUE like MotionEstimateLcu does (:6820).
+ *   SADs are the reference's vertically 2:1 sub-sampled, doubled SADs; MV word =
+ *   (uint16)(4*y) << 16 | (uint16)(4*x) with strict-'<' raster-order tie breaking (first minimum wins).
+ */
+typedef struct svthip_fullpel_desc {
+    int32_t src_offset;
+    int32_t ref_offset;
+    int32_t x_search_area_origin;
+    int32_t y_search_area_origin;
+    int32_t search_area_width;
+    int32_t search_area_height;
+} svthip_fullpel_desc;
+
+int32_t svthip_me_fullpel_search_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                     const uint8_t *d_ref_plane, uint32_t ref_stride,
+                                     const svthip_fullpel_desc *d_desc, uint32_t n_sb, uint32_t max_search_area_width,
+                                     uint32_t max_search_area_height, uint32_t *d_best_sad, uint32_t *d_best_mv,
+                                     void *stream);
+
+/* Host-pointer form: planes are caller-owned host buffers of `src_plane_bytes` / `ref_plane_bytes`. */
+int32_t svthip_me_fullpel_search(svthip_ctx *ctx, const uint8_t *src_plane, size_t src_plane_bytes, uint32_t src_stride,
+                                 const uint8_t *ref_plane, size_t ref_plane_bytes, uint32_t ref_stride,
+                                 const svthip_fullpel_desc *desc, uint32_t n_sb, uint32_t *best_sad, uint32_t *best_mv);
+
+/* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
+ * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
+int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                          const uint8_t *d_ref_plane, uint32_t ref_stride,
+                                          const svthip_fullpel_desc *d_desc, uint32_t n_sb,
+                                          uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                          uint32_t *d_best_sad, uint32_t *d_best_mv, uint32_t iters, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVTAV1_HIP_H */

@@ -1,0 +1,25 @@
+// svt-av1-1_amd/csrc/me_kernels.h -- internal declarations shared by the HIP kernels and the C-ABI glue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// LDS row pitch of the staged reference window.  192 B: >= 16*8 + 64 (widest lane footprint at
+// search_area_width 127) and == 48 dwords, which puts rows y, y+3, y+5, y+6 (one ds_read_b128 lane
+// group) on four distinct bank quarters.
+#define SVTHIP_FULLPEL_LDS_PITCH 192
+#ifndef SVTHIP_FULLPEL_MIN_WAVES
+#define SVTHIP_FULLPEL_MIN_WAVES 3
+#endif
+// fixed LDS in front of the window: 16 KB exchange buffer + 64 B
+#define SVTHIP_FULLPEL_LDS_FIXED (16384 + 64)
+
+namespace svthip {
+
+__global__ void fullpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                 const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
+                                 const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
+                                 uint32_t* __restrict__ out_mv);
+
+inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
+
+}  // namespace svthip

@@ -1,0 +1,108 @@
+"""GPU parity: the HIP full-pel 85-PU search (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import svtav1_hip
+from svtav1_hip import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pictures(w, h, kind, seed=1234):
+    if kind == "synth":
+        return synth.PaPicture(synth.synth_luma(w, h, 1)), synth.PaPicture(synth.synth_luma(w, h, 0))
+    if kind == "flat":
+        a = np.full((h, w), 77, np.uint8)
+        return synth.PaPicture(a), synth.PaPicture(a.copy())
+    if kind == "coarse":  # few grey levels -> many exact SAD ties at non-trivial positions
+        rng = np.random.default_rng(seed)
+        return (synth.PaPicture((rng.integers(0, 3, (h, w)) * 100).astype(np.uint8)),
+                synth.PaPicture((rng.integers(0, 3, (h, w)) * 100).astype(np.uint8)))
+    rng = np.random.default_rng(seed)
+    return (synth.PaPicture(rng.integers(0, 256, (h, w), dtype=np.uint8)),
+            synth.PaPicture(rng.integers(0, 256, (h, w), dtype=np.uint8)))
+
+
+def _compare(hip_ctx, oracle, cur, ref, desc):
+    s_h, m_h = hip_ctx.fullpel_search(cur.full, ref.full, desc)
+    s_o, m_o = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    bad = np.argwhere((s_h != s_o) | (m_h != m_o))
+    assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}: hip sad/mv {s_h[tuple(bad[0])]}/{m_h[tuple(bad[0])]:#x} oracle {s_o[tuple(bad[0])]}/{m_o[tuple(bad[0])]:#x}"
+
+
+@pytest.mark.parametrize("kind", ["synth", "flat", "coarse", "random"])
+@pytest.mark.parametrize("search", [(64, 64), (16, 16), (23, 9), (127, 127), (7, 5), (1, 1), (100, 33)])
+def test_fullpel_matches_oracle(hip_ctx, oracle, kind, search):
+    w, h = 192, 136
+    cur, ref = _pictures(w, h, kind)
+    rng = np.random.default_rng(11)
+    nx, ny = cur.sb_grid()
+    centers = rng.integers(-40, 41, size=(nx * ny, 2))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, centers, *search)
+    _compare(hip_ctx, oracle, cur, ref, desc)
+
+
+def test_fullpel_854x480_all_sbs(hip_ctx, oracle):
+    """BASELINE config-1 picture size (856x480 internally: partial right column and bottom row)."""
+    cur, ref = _pictures(856, 480, "synth")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    _compare(hip_ctx, oracle, cur, ref, desc)
+
+
+def test_fullpel_unaligned_reference_offsets(hip_ctx, oracle):
+    """Every byte alignment of the search-window origin (the LDS staging re-aligns with v_alignbyte)."""
+    cur, ref = _pictures(256, 128, "random", seed=5)
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, [(dx, 0) for dx in range(-3, 5)], 33, 17)
+    _compare(hip_ctx, oracle, cur, ref, desc)
+
+
+def test_fullpel_1080p_properties(hip_ctx, oracle):
+    """Full BASELINE size: a sample of SBs against the oracle, plus size-independent properties over
+    all 510 SBs: identical pictures give SAD 0 at MV (0,0) or an earlier tie; larger PUs equal sums
+    is not required (independent minima) but every PU's SAD must be <= the SAD at the 64x64's MV."""
+    cur, ref = _pictures(1920, 1080, "synth")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    s_h, m_h = hip_ctx.fullpel_search(cur.full, ref.full, desc)
+    sample = np.random.default_rng(3).choice(desc.shape[0], 48, replace=False)
+    s_o, m_o = oracle.fullpel_search_batch(cur.full, ref.full, desc[sample])
+    assert np.array_equal(s_h[sample], s_o) and np.array_equal(m_h[sample], m_o)
+    # property: sum of the four 32x32 minima <= the 64x64 minimum, 16x16 likewise (minimum of a sum)
+    assert (s_h[:, 1:5].sum(1) <= s_h[:, 0]).all()
+    assert (s_h[:, 5:21].sum(1) <= s_h[:, 1:5].sum(1)).all()
+    assert (s_h[:, 21:85].sum(1) <= s_h[:, 5:21].sum(1)).all()
+    # identical pictures: zero SAD everywhere
+    s_z, m_z = hip_ctx.fullpel_search(cur.full, cur.full, desc)
+    assert (s_z == 0).all()
+
+
+def test_device_pointer_entry(hip_ctx, oracle):
+    torch = pytest.importorskip("torch")
+    cur, ref = _pictures(256, 192, "synth")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(cur.full).to(dev)
+    d_ref = torch.from_numpy(ref.full).to(dev)
+    d_desc = torch.from_numpy(desc).to(dev)
+    n = desc.shape[0]
+    d_sad = torch.zeros((n, 85), dtype=torch.int32, device=dev)
+    d_mv = torch.zeros((n, 85), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hip_ctx.fullpel_search_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), n, 64, 64,
+                               d_sad.data_ptr(), d_mv.data_ptr())
+    hip_ctx.synchronize()
+    s_o, m_o = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    assert np.array_equal(d_sad.cpu().numpy().view(np.uint32), s_o)
+    assert np.array_equal(d_mv.cpu().numpy().view(np.uint32), m_o)
+
+
+def test_bad_arguments_fail_loudly(hip_ctx):
+    cur, ref = _pictures(128, 128, "flat")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    bad = desc.copy()
+    bad[0, 4] = 200  # search width > 127
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fullpel_search(cur.full, ref.full, bad)
+    bad = desc.copy()
+    bad[0, 1] = cur.full.size  # window outside the plane
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fullpel_search(cur.full, ref.full, bad)
