@@ -24,14 +24,14 @@ sys.path.insert(0, os.path.join(ROOT, "svt-av1-1_amd", "python"))
 import numpy as np  # noqa: E402
 
 W, H = 1920, 1080
-PICTURES_PER_STEP = 8
+PICTURES_PER_STEP = 12
 SEARCH_W = SEARCH_H = 64
 ALGO_BYTES_PER_BLOCK = 4096 + 127 * 127 + 680  # src + ref window + results = 20905 B
 ABSDIFF_PER_BLOCK = SEARCH_W * SEARCH_H * 2048  # 64 8x8 SADs x 32 abs-diffs per position
 HBM_PEAK_GBPS = 8000.0
 # measured packed-SAD issue ceiling (tools/ubench_valu.hip, profiles/ubench_valu_r01.txt):
-# v_qsad_pk_u16_u8 = 16 abs-diff/lane per 10.8 SIMD-cycles at >=3 waves/SIMD
-VALU_PEAK_ABSDIFF_PER_S = 256 * 4 * 64 * 16 / 10.8 * 2.4e9
+# v_qsad_pk_u16_u8 = 16 abs-diff/lane per 16.15 SIMD-cycles, independent of occupancy (profiles/r01_ubench_occupancy.txt)
+VALU_PEAK_ABSDIFF_PER_S = 256 * 4 * 64 * 16 / 16.15 * 2.4e9
 
 
 def build_pool(n_pictures, rank_seed):

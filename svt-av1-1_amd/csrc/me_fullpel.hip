@@ -29,7 +29,6 @@ namespace svthip {
 namespace {
 
 constexpr int kPitch = SVTHIP_FULLPEL_LDS_PITCH;  // bytes per window row in LDS
-constexpr uint32_t kPenalty = 8200u;  // > max 8x8 raw SAD (8160); 4*(8200+8160) < 65536 so packed u16 sums stay exact
 
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
@@ -152,24 +151,16 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
         const int y = pg / n_xg;
         const int xg = pg - y * n_xg;
 
-        // per-position raster index and validity penalty
+        // per-position raster index; positions outside the search area get idx = ~0 so that every key
+        // OR-ed with it is 0xffffffff and can never win (at least one position is always valid)
         uint32_t idx[16];
-        uint64_t accinit[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t pen[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int x = 16 * xg + 4 * q + j;
-                idx[4 * q + j] = (uint32_t)(y * 128 + x);
-                pen[j] = (lane_valid && x < sw) ? 0u : kPenalty;
-            }
-            accinit[q] = pack64(pen[0] | (pen[1] << 16), pen[2] | (pen[3] << 16));
+        for (int i = 0; i < 16; i++) {
+            const int x = 16 * xg + i;
+            idx[i] = (lane_valid && x < sw) ? (uint32_t)(y * 128 + x) : 0xffffffffu;
         }
 
-        uint32_t s32acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) s32acc[i] = 0;
+        uint32_t s16lo[4][4], s16hi[4][4];  // [zz][q] packed u16 16x16 sums
 
         const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
 
@@ -177,10 +168,6 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
         for (int zz = 0; zz < 4; zz++) {
             const int C = zz & 1, R = zz >> 1;
             uint64_t acc[4][4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) acc[k][q] = accinit[q];
 
 #pragma unroll
             for (int r8 = 0; r8 < 8; r8++) {
@@ -198,7 +185,9 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
 #pragma unroll
                     for (int h = 0; h < 4; h++) {
                         const int k = krow + (h >> 1);
-                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(W[q + h], W[q + h + 1]), S[h], acc[k][q]);
+                        const bool first = ((r8 & 3) == 0) && ((h & 1) == 0);  // first touch of acc[k][q]
+                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(W[q + h], W[q + h + 1]), S[h],
+                                                                    first ? 0ull : acc[k][q]);
                     }
             }
 
@@ -215,14 +204,24 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
                 const uint32_t hi = (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32) +
                                     (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32);
                 best16[zz] = track4(best16[zz], pack64(lo, hi), &idx[4 * q], himask);
-                s32acc[4 * q + 0] += lo & 0xffffu;
-                s32acc[4 * q + 1] += lo >> 16;
-                s32acc[4 * q + 2] += hi & 0xffffu;
-                s32acc[4 * q + 3] += hi >> 16;
+                s16lo[zz][q] = lo;
+                s16hi[zz][q] = hi;
             }
         }
 
-        // 32x32 PU of this quadrant: key = raw << 14 | idx  (raw <= 4*4*(8160+8200) < 2^18 with penalties)
+        // 32x32 = sum of the four 16x16: pairs are added packed (<= 2*32640 fits u16), then widened
+        uint32_t s32acc[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a_lo = s16lo[0][q] + s16lo[1][q], b_lo = s16lo[2][q] + s16lo[3][q];
+            const uint32_t a_hi = s16hi[0][q] + s16hi[1][q], b_hi = s16hi[2][q] + s16hi[3][q];
+            s32acc[4 * q + 0] = (a_lo & 0xffffu) + (b_lo & 0xffffu);
+            s32acc[4 * q + 1] = (a_lo >> 16) + (b_lo >> 16);
+            s32acc[4 * q + 2] = (a_hi & 0xffffu) + (b_hi & 0xffffu);
+            s32acc[4 * q + 3] = (a_hi >> 16) + (b_hi >> 16);
+        }
+
+        // 32x32 PU of this quadrant: key = raw << 14 | idx  (raw <= 130560 < 2^17)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             uint32_t k0 = (s32acc[i] << 14) | idx[i];
@@ -247,10 +246,12 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
             }
             const uint32_t sv[4] = {s.x, s.y, s.z, s.w};
             // idx of position 4Q+j of this lane: idx[] is indexed statically, so select by Q
-            const uint32_t ibase = (uint32_t)(y * 128 + 16 * xg + 4 * Q);
+            const int xbase = 16 * xg + 4 * Q;
+            const uint32_t ibase = (uint32_t)(y * 128 + xbase);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool better = sv[j] < best64_raw;  // strict '<', positions visited in raster order per lane
+                // strict '<', positions visited in raster order per lane; positions outside the area never win
+                const bool better = (sv[j] < best64_raw) && lane_valid && (xbase + j < sw);
                 best64_raw = better ? sv[j] : best64_raw;
                 best64_idx = better ? (ibase + j) : best64_idx;
             }
