@@ -12,7 +12,7 @@
 
 #define ITER 512
 #ifndef WPS_MAX
-#define WPS_MAX 3
+#define WPS_MAX 8
 #endif
 #define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -39,45 +39,6 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, Rec* rec, uint32_t seed)
             else if (OP == 1) { a[i] = __builtin_amdgcn_sad_u8(a[i], b[i], a[i]); }
             else if (OP == 2) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i])); }
             else if (OP == 3) { asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(s)); }
-            else if (OP == 10) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 11) { asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 12) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 13) { asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 14) { asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 15) { asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 16) { asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 17) { asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 18) { asm volatile("v_min_i32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 19) { asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 20) { asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 21) { asm volatile("v_min_u16 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 22) { asm volatile("v_add_u16 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 23) { asm volatile("v_min_f16 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 24) { asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 25) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 26) { asm volatile("v_cmp_lt_u32 vcc, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 27) { asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 28) { asm volatile("v_bfi_b32 %0, %2, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 29) { asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 30) { asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 31) { asm volatile("v_min_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 32) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 33) { asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 34) { asm volatile("v_pk_add_f32 %3, %3, %3" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 35) { asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 36) { asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 37) { asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 38) { asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 39) { asm volatile("v_add_lshl_u32 %0, %0, %1, 3" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 40) { asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 41) { asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 42) { asm volatile("v_min_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 43) { asm volatile("v_pk_mov_b32 %3, %3, %3 op_sel:[1,0]" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 44) { asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 45) { asm volatile("v_sad_hi_u8 %0, %1, %2, %0" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 46) { asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 47) { asm volatile("v_pk_lshlrev_b16 %0, 3, %0 op_sel_hi:[0,1]" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
-            else if (OP == 48) { asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]), "+v"(b[i]) : "v"(s), "v"(p[i]) : "vcc"); }
             else if (OP == 4) { /* kernel-like mix: 4 qsad + 3 VOP3 + 1 add */
                 p[i] = __builtin_amdgcn_qsad_pk_u16_u8(q[i], s, p[i]);
                 p[i] = __builtin_amdgcn_qsad_pk_u16_u8(q[i], a[i], p[i]);
@@ -155,45 +116,6 @@ int main()
     run<2>("v_add_u32", 1, ncu, out, rec);
     run<3>("v_min3_u32", 1, ncu, out, rec);
     run<4>("mix 4qsad+3vop3+1add (x8)", 8, ncu, out, rec);
-    run<10>("v_and_b32", 1, ncu, out, rec);
-    run<11>("v_or_b32", 1, ncu, out, rec);
-    run<12>("v_xor_b32", 1, ncu, out, rec);
-    run<13>("v_lshlrev_b32", 1, ncu, out, rec);
-    run<14>("v_lshrrev_b32", 1, ncu, out, rec);
-    run<15>("v_sub_u32", 1, ncu, out, rec);
-    run<16>("v_min_u32", 1, ncu, out, rec);
-    run<17>("v_max_u32", 1, ncu, out, rec);
-    run<18>("v_min_i32", 1, ncu, out, rec);
-    run<19>("v_min_f32", 1, ncu, out, rec);
-    run<20>("v_min3_f32", 1, ncu, out, rec);
-    run<21>("v_min_u16", 1, ncu, out, rec);
-    run<22>("v_add_u16", 1, ncu, out, rec);
-    run<23>("v_min_f16", 1, ncu, out, rec);
-    run<24>("v_pk_min_f16", 1, ncu, out, rec);
-    run<25>("v_cndmask_b32", 1, ncu, out, rec);
-    run<26>("v_cmp_lt_u32", 1, ncu, out, rec);
-    run<27>("v_mul_u32_u24", 1, ncu, out, rec);
-    run<28>("v_bfi_b32", 1, ncu, out, rec);
-    run<29>("v_alignbit_b32", 1, ncu, out, rec);
-    run<30>("v_add_u32_sdwa", 1, ncu, out, rec);
-    run<31>("v_min_u16_sdwa_hi", 1, ncu, out, rec);
-    run<32>("v_add_f32", 1, ncu, out, rec);
-    run<33>("v_fma_f32", 1, ncu, out, rec);
-    run<34>("v_pk_add_f32", 1, ncu, out, rec);
-    run<35>("v_max3_u32", 1, ncu, out, rec);
-    run<36>("v_med3_u32", 1, ncu, out, rec);
-    run<37>("v_or3_b32", 1, ncu, out, rec);
-    run<38>("v_lshl_add_u32", 1, ncu, out, rec);
-    run<39>("v_add_lshl_u32", 1, ncu, out, rec);
-    run<40>("v_xad_u32", 1, ncu, out, rec);
-    run<41>("v_mov_b32_dpp", 1, ncu, out, rec);
-    run<42>("v_min_u32_dpp", 1, ncu, out, rec);
-    run<43>("v_pk_mov_b32", 1, ncu, out, rec);
-    run<44>("v_perm_b32", 1, ncu, out, rec);
-    run<45>("v_sad_hi_u8", 1, ncu, out, rec);
-    run<46>("v_pk_min_u16", 1, ncu, out, rec);
-    run<47>("v_pk_lshlrev_b16", 1, ncu, out, rec);
-    run<48>("v_pk_mad_u16", 1, ncu, out, rec);
 
     return 0;
 }
