@@ -89,6 +89,59 @@ int32_t svthip_me_fullpel_search(svthip_ctx *ctx, const uint8_t *src_plane, size
                                  const uint8_t *ref_plane, size_t ref_plane_bytes, uint32_t ref_stride,
                                  const svthip_fullpel_desc *desc, uint32_t n_sb, uint32_t *best_sad, uint32_t *best_mv);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Hierarchical ME (HME): search-centre derivation for a batch of superblocks against one list.
+ * Replaces the first half of MotionEstimateLcu (Codec/EbMotionEstimation.c:6300-6738):
+ * hme_mv_center_check (:5882-6145), HmeLevel0/1/2 (:4306-4758) over the 2x2 search regions, the
+ * best-region pick (:6573-6631), CheckZeroZeroCenter (:5466-5552) and the search-window clipping
+ * (:6667-6723).  Output is the svthip_fullpel_desc array consumed by svthip_me_fullpel_search*.
+ *
+ * The three planes of a picture are what EbPaReferenceObject_t holds (Codec/EbReferenceObject.c:220-258):
+ * padded full-resolution luma (origin 68,68), "quarter" (every 2nd pixel/row, origin 32,32) and
+ * "sixteenth" (every 4th, origin 16,16).  Offsets are in bytes from `pool`, so one device buffer can
+ * hold many pictures (the reference's picture pools).
+ */
+typedef struct svthip_pa_picture {
+    int64_t full_offset;      /* byte offset of the padded full-res plane's first byte in the pool */
+    int64_t quarter_offset;
+    int64_t sixteenth_offset;
+    uint32_t full_stride, quarter_stride, sixteenth_stride;
+    uint16_t width, height;   /* luma_width / luma_height (multiples of 8) */
+} svthip_pa_picture;
+
+/* MeContext_t search parameters (Codec/EbMotionEstimationProcess.c:94-156) + the picture-level
+ * signals MotionEstimateLcu reads from PictureParentControlSet_t. */
+typedef struct svthip_me_params {
+    uint16_t search_area_width, search_area_height;                 /* full-pel search area (<=127 used) */
+    uint16_t number_hme_search_region_in_width, number_hme_search_region_in_height; /* 1..2 each */
+    uint16_t hme_level0_total_search_area_width, hme_level0_total_search_area_height;
+    uint16_t hme_level0_search_area_in_width_array[2], hme_level0_search_area_in_height_array[2];
+    uint16_t hme_level1_search_area_in_width_array[2], hme_level1_search_area_in_height_array[2];
+    uint16_t hme_level2_search_area_in_width_array[2], hme_level2_search_area_in_height_array[2];
+    uint32_t hme_level0_multiplier_x, hme_level0_multiplier_y;      /* HME_LEVEL_0_SEARCH_AREA_MULTIPLIER_X/Y[hier][tl] */
+    uint8_t enable_hme_flag, enable_hme_level0_flag, enable_hme_level1_flag, enable_hme_level2_flag;
+    uint8_t temporal_layer_index;
+    uint8_t is_used_as_reference_flag;
+    uint8_t ref_poc_equal;   /* ref0Poc == ref1Poc: list 1 takes the second-best HME L2 region (:6606-6631) */
+    uint8_t reserved;
+} svthip_me_params;
+
+/* One SB of the batch: origin in luma samples (multiples of 64). */
+typedef struct svthip_sb_origin {
+    uint16_t x, y;
+} svthip_sb_origin;
+
+/* d_l0_best_mv64: for list_index 1, the final list-0 MV word of the 64x64 PU of every SB
+ * (p_sb_best_mv[0][0][0], used by hme_mv_center_check :6076-6077); may be NULL for list 0.
+ * Outputs: d_desc[n_sb] (ready for svthip_me_fullpel_search_dev with the SAME pool as both planes),
+ *          d_center[n_sb] = (int16 x, int16 y) final search centre, for inspection (may be NULL). */
+int32_t svthip_me_hme_search_center_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                        const svthip_pa_picture *ref, const svthip_me_params *params,
+                                        uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
+                                        const uint32_t *d_l0_best_mv64, svthip_fullpel_desc *d_desc,
+                                        int16_t *d_center, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

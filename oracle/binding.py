@@ -46,15 +46,38 @@ class Oracle:
         L.orc_fullpel_search_batch.restype = None
         L.orc_fullpel_search_batch.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, i32p, C.c_uint32, u32p, u32p]
 
-    def fullpel_search_batch(self, src_plane, ref_plane, desc):
-        """desc: int32 [n,6] = src_offset, ref_offset, x_origin, y_origin, sw, sh -> (sad[n,85], mv[n,85])."""
+    def fullpel_search_batch(self, src_plane, ref_plane, desc, src_stride=None, ref_stride=None):
+        """desc: int32 [n,6] = src_offset, ref_offset, x_origin, y_origin, sw, sh -> (sad[n,85], mv[n,85]).
+        Planes are 2-D arrays (stride = row length) or a flat pool with explicit strides."""
         desc = np.ascontiguousarray(desc, dtype=np.int32)
         n = desc.shape[0]
         sad = np.empty((n, 85), dtype=np.uint32)
         mv = np.empty((n, 85), dtype=np.uint32)
-        self.lib.orc_fullpel_search_batch(_ptr(src_plane, u8p), src_plane.shape[1], _ptr(ref_plane, u8p),
-                                          ref_plane.shape[1], _ptr(desc, i32p), n, _ptr(sad, u32p), _ptr(mv, u32p))
+        ss = src_stride if src_stride is not None else src_plane.shape[1]
+        rs = ref_stride if ref_stride is not None else ref_plane.shape[1]
+        self.lib.orc_fullpel_search_batch(_ptr(src_plane, u8p), ss, _ptr(ref_plane, u8p), rs, _ptr(desc, i32p), n,
+                                          _ptr(sad, u32p), _ptr(mv, u32p))
         return sad, mv
+
+    def hme_search_center_batch(self, pool, cur, ref, params, list_index, sb, l0_best_mv64=None, hme_state=None):
+        """-> (desc int32 [n,6], center int16 [n,2]); cur/ref are svtav1_hip.PaPictureDesc, params MeParams."""
+        sb = np.ascontiguousarray(sb, dtype=np.uint16)
+        n = sb.shape[0]
+        desc = np.zeros((n, 6), dtype=np.int32)
+        center = np.zeros((n, 2), dtype=np.int16)
+        mvp = None
+        if l0_best_mv64 is not None:
+            l0_best_mv64 = np.ascontiguousarray(l0_best_mv64, dtype=np.uint32)
+            mvp = l0_best_mv64.ctypes.data_as(C.c_void_p)
+        f = self.lib.orc_hme_search_center_batch
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                      C.c_void_p, C.c_void_p, C.c_void_p]
+        if hme_state is not None:
+            assert hme_state.dtype == np.int16 and hme_state.shape == (n, 25) and hme_state.flags.c_contiguous
+        f(pool.ctypes.data, C.byref(cur), C.byref(ref), C.byref(params), list_index, sb.ctypes.data, n, mvp,
+          desc.ctypes.data, center.ctypes.data, hme_state.ctypes.data if hme_state is not None else None)
+        return desc, center
 
     def sad_loop(self, src, src_off, src_stride, ref, ref_off, ref_stride, height, width, ref_stride_raw, sw, sh):
         best = C.c_uint64(0)
@@ -104,3 +127,57 @@ class Reference:
         getattr(self.lib, name)(sp, src_stride, rp, ref_stride, height, width, C.byref(best), C.byref(x),
                                 C.byref(y), ref_stride_raw, sw, sh)
         return best.value, x.value, y.value
+
+
+REF_ME_SO = os.path.join(HERE, "_ref", "libsvtref_me.so")
+
+
+class ReferenceME:
+    """The reference's own MotionEstimateLcu (oracle/_ref/libsvtref_me.so, sub-pel disabled: see
+    oracle/ref_me_lcu_driver.c for why)."""
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_ME_SO)
+
+    def __init__(self):
+        # lazy binding: three NASM-only symbols stay unresolved by design and are never reached
+        self.lib = C.CDLL(REF_ME_SO, mode=os.RTLD_LAZY)
+        self.lib.ref_me_lcu_run.restype = C.c_int
+        self.lib.ref_me_lcu_run.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+
+    def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0):
+        """cur/ref0/ref1: svtav1_hip.synth.PaPicture; params: svtav1_hip.MeParams.
+        -> dict(sad [n,2,85], mv [n,2,85], origin [n,2,2], res [n,85,9])"""
+        w, h = cur.width, cur.height
+        planes = (C.c_void_p * 9)()
+        keep = []
+        for i, p in enumerate((cur, ref0, ref1)):
+            for j, a in enumerate((p.full, p.quarter, p.sixteenth)):
+                a = np.ascontiguousarray(a)
+                keep.append(a)
+                planes[3 * i + j] = a.ctypes.data
+        P = params
+        ip = np.array([P.search_area_width, P.search_area_height, P.number_hme_search_region_in_width,
+                       P.number_hme_search_region_in_height, P.hme_level0_total_search_area_width,
+                       P.hme_level0_total_search_area_height,
+                       P.hme_level0_search_area_in_width_array[0], P.hme_level0_search_area_in_width_array[1],
+                       P.hme_level0_search_area_in_height_array[0], P.hme_level0_search_area_in_height_array[1],
+                       P.hme_level1_search_area_in_width_array[0], P.hme_level1_search_area_in_width_array[1],
+                       P.hme_level1_search_area_in_height_array[0], P.hme_level1_search_area_in_height_array[1],
+                       P.hme_level2_search_area_in_width_array[0], P.hme_level2_search_area_in_width_array[1],
+                       P.hme_level2_search_area_in_height_array[0], P.hme_level2_search_area_in_height_array[1],
+                       P.enable_hme_flag, P.enable_hme_level0_flag, P.enable_hme_level1_flag, P.enable_hme_level2_flag,
+                       int(two_lists), P.temporal_layer_index, hierarchical_levels, P.is_used_as_reference_flag, 0,
+                       10, 10 if P.ref_poc_equal else 20, asm_type], dtype=np.int32)
+        n = ((w + 63) // 64) * ((h + 63) // 64)
+        sad = np.zeros((n, 2, 85), np.uint32)
+        mv = np.zeros((n, 2, 85), np.uint32)
+        origin = np.zeros((n, 2, 4), np.int32)
+        res = np.zeros((n, 85, 9), np.int32)
+        rc = self.lib.ref_me_lcu_run(planes, w, h, ip.ctypes.data, sad.ctypes.data, mv.ctypes.data, origin.ctypes.data,
+                                     res.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"ref_me_lcu_run failed: {rc}")
+        return {"sad": sad, "mv": mv, "origin": origin[:, :, :2], "res": res}

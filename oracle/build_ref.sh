@@ -48,7 +48,7 @@ for f in "${FILES[@]}"; do
 done
 # our own drivers that replay the call sequence of the reference's *static* L2 functions over the
 # reference kernels (they contain no reference code, only calls into it)
-for f in "$HERE"/ref_*_driver.c; do
+for f in "$HERE"/ref_fullpel_driver.c; do
   o="$OUT/obj/$(basename "$f" .c).o"
   gcc -O2 -std=gnu99 -Wall -mavx2 -fPIC -ffunction-sections -c "$f" -o "$o"
   OBJS+=("$o")
@@ -85,3 +85,20 @@ EOF
 gcc -shared -o "$OUT/libsvtref_kernels.so" "${OBJS[@]}" \
     -Wl,--gc-sections -Wl,--version-script="$OUT/obj/kernels.map" -Wl,-z,defs -lc
 echo "built $OUT/libsvtref_kernels.so"
+
+# ---------------------------------------------------------------------------------------------
+# libsvtref_me.so : the reference's MotionEstimateLcu (Codec/EbMotionEstimation.c:6152) with everything it
+# reaches, driven by oracle/ref_me_lcu_driver.c.  All 144 reference .c files are compiled where they lie;
+# --gc-sections keeps only what MotionEstimateLcu / MeContextCtor reach.  Two symbols that exist only in the
+# reference's NASM sources stay UNRESOLVED (no stand-ins are written): Log2f_SSE2 and
+# PictureCopyKernel_SSE2.  They are call targets only, so the library loads with lazy binding and works
+# as long as neither is reached: the driver refuses use_subpel_flag=1 (PU_HalfPelRefinement calls Log2f).
+mkdir -p "$OUT/obj_all"
+export OUT CFLAGS INC
+ls "$S"/Lib/{C_DEFAULT,ASM_SSE2,ASM_SSSE3,ASM_SSE4_1,ASM_AVX2,Codec}/*.c | xargs -P "$(nproc)" -I{} sh -c \
+  'o="$OUT/obj_all/$(basename {} .c).o"; if [ ! -f "$o" ] || [ {} -nt "$o" ]; then gcc $CFLAGS $INC -c {} -o "$o"; fi'
+gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_me_lcu_driver.c" -o "$OUT/obj/ref_me_lcu_driver.o"
+printf '{ global: ref_me_lcu_run; local: *; };\n' > "$OUT/obj/me.map"
+gcc -shared -o "$OUT/libsvtref_me.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_me_lcu_driver.o" \
+    -Wl,--gc-sections -Wl,--version-script="$OUT/obj/me.map" -lm -lpthread
+echo "built $OUT/libsvtref_me.so (unresolved by design: $(nm -D "$OUT/libsvtref_me.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"

@@ -15,6 +15,7 @@
 #ifndef SVT_ME_ORACLE_H
 #define SVT_ME_ORACLE_H
 #include <stdint.h>
+#include "../include/svtav1_hip.h" /* public ABI types only (descriptors, parameter blocks) */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -52,6 +53,17 @@ void orc_init_best(uint32_t *best_sad, uint32_t *best_mv, uint32_t n);
 void orc_fullpel_search_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane,
                               uint32_t ref_stride, const int32_t *desc, uint32_t n_sb, uint32_t *best_sad,
                               uint32_t *best_mv);
+
+/* Search-centre half of MotionEstimateLcu for one SB and one list (Codec/EbMotionEstimation.c:6300-6738):
+ * hme_mv_center_check, HmeLevel0/1/2 per region, region pick, CheckZeroZeroCenter, window clipping.
+ * Writes the full-pel descriptor (offsets relative to `pool`) and optionally the final centre. */
+void orc_hme_search_center(const uint8_t *pool, const svthip_pa_picture *cur, const svthip_pa_picture *ref,
+                           const svthip_me_params *p, uint32_t list_index, uint32_t sb_origin_x, uint32_t sb_origin_y,
+                           uint32_t l0_best_mv64, svthip_fullpel_desc *desc, int16_t *center_xy, int16_t *hme_state);
+void orc_hme_search_center_batch(const uint8_t *pool, const svthip_pa_picture *cur, const svthip_pa_picture *ref,
+                                 const svthip_me_params *p, uint32_t list_index, const svthip_sb_origin *sb, uint32_t n_sb,
+                                 const uint32_t *l0_best_mv64, svthip_fullpel_desc *desc, int16_t *center_xy,
+                                 int16_t *hme_state /* [n_sb][25], carried from list 0 to list 1; may be NULL */);
 
 #ifdef __cplusplus
 }

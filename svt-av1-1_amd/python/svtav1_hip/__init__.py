@@ -147,3 +147,100 @@ def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.nd
             out[i] = [(synth.PAD_FULL + oy) * cur.stride + synth.PAD_FULL + ox,
                       (synth.PAD_FULL + oy + yo) * ref.stride + synth.PAD_FULL + ox + xo, xo, yo, sw, sh]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Hierarchical ME: ctypes mirrors of the parameter blocks in include/svtav1_hip.h
+# ------------------------------------------------------------------------------------------------
+class PaPictureDesc(C.Structure):
+    _fields_ = [("full_offset", C.c_int64), ("quarter_offset", C.c_int64), ("sixteenth_offset", C.c_int64),
+                ("full_stride", C.c_uint32), ("quarter_stride", C.c_uint32), ("sixteenth_stride", C.c_uint32),
+                ("width", C.c_uint16), ("height", C.c_uint16)]
+
+
+class MeParams(C.Structure):
+    _fields_ = [("search_area_width", C.c_uint16), ("search_area_height", C.c_uint16),
+                ("number_hme_search_region_in_width", C.c_uint16), ("number_hme_search_region_in_height", C.c_uint16),
+                ("hme_level0_total_search_area_width", C.c_uint16), ("hme_level0_total_search_area_height", C.c_uint16),
+                ("hme_level0_search_area_in_width_array", C.c_uint16 * 2), ("hme_level0_search_area_in_height_array", C.c_uint16 * 2),
+                ("hme_level1_search_area_in_width_array", C.c_uint16 * 2), ("hme_level1_search_area_in_height_array", C.c_uint16 * 2),
+                ("hme_level2_search_area_in_width_array", C.c_uint16 * 2), ("hme_level2_search_area_in_height_array", C.c_uint16 * 2),
+                ("hme_level0_multiplier_x", C.c_uint32), ("hme_level0_multiplier_y", C.c_uint32),
+                ("enable_hme_flag", C.c_uint8), ("enable_hme_level0_flag", C.c_uint8), ("enable_hme_level1_flag", C.c_uint8),
+                ("enable_hme_level2_flag", C.c_uint8), ("temporal_layer_index", C.c_uint8),
+                ("is_used_as_reference_flag", C.c_uint8), ("ref_poc_equal", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class SbOrigin(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16)]
+
+
+# HME_LEVEL_0_SEARCH_AREA_MULTIPLIER_X / _Y [hierarchical_levels][temporal_layer_index]
+# (Codec/EbDefinitions.h:2980-2996); X and Y tables are identical in the reference.
+HME_LEVEL0_MULTIPLIER = [[100], [100, 100], [100, 100, 100], [200, 140, 100, 70], [350, 200, 100, 100, 100],
+                         [525, 350, 200, 100, 100, 100]]
+
+
+def default_me_params(width: int, height: int, hierarchical_levels: int = 3, temporal_layer_index: int = 0,
+                      is_ref: bool = True, ref_poc_equal: bool = False) -> MeParams:
+    """set_me_hme_params_oq() for enc modes M0..M3 (column 0 of the tables, Codec/EbDefinitions.h:3332-3465;
+    resolution class per Codec/EbMotionEstimationProcess.c:104-110)."""
+    px = width * height
+    ratio = width // height
+    if px < 1280 * 720 * 0.75:  # INPUT_SIZE_576p_RANGE_OR_LOWER (Codec/EbDefinitions.h input-size thresholds)
+        ri = 0
+    elif px < 1920 * 1080 * 0.75 and ratio < 2:
+        ri = 1
+    elif px <= 1920 * 1088 * 1.5:
+        ri = 3
+    else:
+        ri = 4
+    tot_w = [48, 64, 96, 96, 128][ri]
+    tot_h = [40, 48, 48, 48, 80][ri]
+    p = MeParams()
+    p.search_area_width, p.search_area_height = 64, 64
+    p.number_hme_search_region_in_width = p.number_hme_search_region_in_height = 2
+    p.hme_level0_total_search_area_width, p.hme_level0_total_search_area_height = tot_w, tot_h
+    for k in range(2):
+        p.hme_level0_search_area_in_width_array[k] = tot_w // 2
+        p.hme_level0_search_area_in_height_array[k] = tot_h // 2
+        p.hme_level1_search_area_in_width_array[k] = 16
+        p.hme_level1_search_area_in_height_array[k] = 16
+        p.hme_level2_search_area_in_width_array[k] = 8
+        p.hme_level2_search_area_in_height_array[k] = 8
+    m = HME_LEVEL0_MULTIPLIER[hierarchical_levels][temporal_layer_index]
+    p.hme_level0_multiplier_x = p.hme_level0_multiplier_y = m
+    p.enable_hme_flag = p.enable_hme_level0_flag = p.enable_hme_level1_flag = p.enable_hme_level2_flag = 1
+    p.temporal_layer_index = temporal_layer_index
+    p.is_used_as_reference_flag = int(is_ref)
+    p.ref_poc_equal = int(ref_poc_equal)
+    return p
+
+
+def build_picture_pool(pictures):
+    """Stack the three planes of each PaPicture into one uint8 pool (4-byte aligned planes).
+    Returns (pool, [PaPictureDesc])."""
+    chunks, descs, off = [], [], 0
+    for p in pictures:
+        d = PaPictureDesc()
+        for name, arr in (("full", p.full), ("quarter", p.quarter), ("sixteenth", p.sixteenth)):
+            flat = arr.reshape(-1)
+            padn = (-flat.size) % 16
+            setattr(d, name + "_offset", off)
+            setattr(d, name + "_stride", arr.shape[1])
+            chunks.append(flat)
+            if padn:
+                chunks.append(np.zeros(padn, np.uint8))
+            off += flat.size + padn
+        d.width, d.height = p.width, p.height
+        descs.append(d)
+    return np.concatenate(chunks), descs
+
+
+def sb_origins(width: int, height: int) -> np.ndarray:
+    nx, ny = (width + 63) // 64, (height + 63) // 64
+    out = np.zeros((nx * ny, 2), dtype=np.uint16)
+    for sy in range(ny):
+        for sx in range(nx):
+            out[sy * nx + sx] = (sx * 64, sy * 64)
+    return out

@@ -1,0 +1,90 @@
+"""Pins the oracle's hierarchical-ME chain (centre check -> HME L0/L1/L2 -> region pick -> zero-centre check
+-> window clipping -> full-pel 85-PU search) against the reference's own MotionEstimateLcu, run standalone from
+oracle/_ref/libsvtref_me.so with sub-pel refinement disabled (the reference's sub-pel path needs a NASM-only
+symbol, see oracle/ref_me_lcu_driver.c).  CPU only."""
+import numpy as np
+import pytest
+
+import svtav1_hip
+from svtav1_hip import synth
+
+
+@pytest.fixture(scope="module")
+def refme():
+    from oracle.binding import ReferenceME
+    if not ReferenceME.available():
+        pytest.skip("oracle/_ref/libsvtref_me.so not built")
+    return ReferenceME()
+
+
+def _pics(w, h, kind):
+    if kind == "synth":
+        f = [synth.synth_luma(w, h, t) for t in (3, 0, 7)]
+    elif kind == "pan":  # large global motion so the HME centres move far from (0,0)
+        big = synth.synth_luma(w + 128, h + 96, 0)
+        f = [big[40:40 + h, 50:50 + w], big[30:30 + h, 14:14 + w], big[70:70 + h, 100:100 + w]]
+    elif kind == "flat":
+        f = [np.full((h, w), 90, np.uint8)] * 3
+    else:
+        rng = np.random.default_rng(99)
+        f = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(3)]
+    return [synth.PaPicture(np.ascontiguousarray(x)) for x in f]
+
+
+def oracle_chain(oracle, pics, P, two_lists):
+    pool, descs = svtav1_hip.build_picture_pool(pics)
+    sb = svtav1_hip.sb_origins(pics[0].width, pics[0].height)
+    out = {}
+    state = np.zeros((sb.shape[0], 25), np.int16)
+    d0, c0 = oracle.hme_search_center_batch(pool, descs[0], descs[1], P, 0, sb, None, state)
+    s0, m0 = oracle.fullpel_search_batch(pool, pool, d0, descs[0].full_stride, descs[1].full_stride)
+    out[0] = (d0, s0, m0)
+    if two_lists:
+        d1, c1 = oracle.hme_search_center_batch(pool, descs[0], descs[2], P, 1, sb, m0[:, 0], state)
+        s1, m1 = oracle.fullpel_search_batch(pool, pool, d1, descs[0].full_stride, descs[2].full_stride)
+        out[1] = (d1, s1, m1)
+    return out
+
+
+CASES = [
+    # (w, h, kind, hierarchical_levels, temporal_layer, two_lists, is_ref, poc_equal)
+    (448, 320, "synth", 3, 0, False, True, False),
+    (448, 320, "pan", 3, 0, False, True, False),
+    (448, 320, "pan", 3, 1, True, True, False),
+    (448, 320, "pan", 4, 0, True, True, False),     # multiplier 350 -> large L0 areas, clipped at the borders
+    (448, 320, "pan", 5, 0, True, False, False),    # multiplier 525, non-reference picture (no zero-centre check)
+    (448, 320, "pan", 3, 3, True, True, True),      # multiplier 70, same-POC list 1 takes the 2nd best region
+    (448, 320, "random", 3, 2, True, True, False),
+    (448, 320, "flat", 3, 1, True, True, False),
+    (456, 328, "pan", 3, 1, True, True, False),     # partial right column (8 px) and bottom row (8 rows)
+    (856, 480, "synth", 3, 0, False, True, False),  # BASELINE config-1 picture size
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_chain_matches_reference_motion_estimate_lcu(oracle, refme, case):
+    w, h, kind, hier, tl, two, is_ref, poc_eq = case
+    pics = _pics(w, h, kind)
+    P = svtav1_hip.default_me_params(w, h, hier, tl, is_ref, poc_eq)
+    ref = refme.run(pics[0], pics[1], pics[2], P, two_lists=two, hierarchical_levels=hier)
+    mine = oracle_chain(oracle, pics, P, two)
+    for l in mine:
+        d, s, m = mine[l]
+        assert np.array_equal(d[:, 2:4], ref["origin"][:, l]), f"list {l}: search-area origins differ"
+        assert np.array_equal(s, ref["sad"][:, l]), f"list {l}: SADs differ"
+        assert np.array_equal(m, ref["mv"][:, l]), f"list {l}: MVs differ"
+
+
+def test_hme_disabled_levels(oracle, refme):
+    pics = _pics(448, 320, "pan")
+    for flags in [(1, 0, 0), (1, 1, 0), (0, 1, 1), (0, 0, 0)]:
+        P = svtav1_hip.default_me_params(448, 320, 3, 1)
+        P.enable_hme_level0_flag, P.enable_hme_level1_flag, P.enable_hme_level2_flag = flags
+        if flags == (0, 0, 0):
+            P.enable_hme_flag = 0
+        ref = refme.run(pics[0], pics[1], pics[2], P, two_lists=True)
+        mine = oracle_chain(oracle, pics, P, True)
+        for l in mine:
+            d, s, m = mine[l]
+            assert np.array_equal(d[:, 2:4], ref["origin"][:, l]), (flags, l)
+            assert np.array_equal(s, ref["sad"][:, l]) and np.array_equal(m, ref["mv"][:, l]), (flags, l)
