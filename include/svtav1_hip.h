@@ -134,13 +134,20 @@ typedef struct svthip_sb_origin {
 
 /* d_l0_best_mv64: for list_index 1, the final list-0 MV word of the 64x64 PU of every SB
  * (p_sb_best_mv[0][0][0], used by hme_mv_center_check :6076-6077); may be NULL for list 0.
+ * d_hme_state  : [n_sb][SVTHIP_HME_STATE_INT16] int16 scratch carried from the list-0 call to the list-1 call
+ *                of the same SBs.  The reference keeps the per-region centre arrays (and the loop counters that
+ *                guard their initialisation, :6325-6345) alive across its list loop, so list 1 starts from list 0's
+ *                values whenever an HME level is disabled.  May be NULL when every enabled level is on (default).
  * Outputs: d_desc[n_sb] (ready for svthip_me_fullpel_search_dev with the SAME pool as both planes),
- *          d_center[n_sb] = (int16 x, int16 y) final search centre, for inspection (may be NULL). */
+ *          d_center[n_sb] = (int16 x, int16 y) final search centre, for inspection (may be NULL).
+ * `cur`, `ref`, `params` are HOST structs (passed by value to the kernel); d_* are device pointers.
+ * The pool must stay readable 4 bytes past the end of every plane (unaligned dword loads). */
+#define SVTHIP_HME_STATE_INT16 25
 int32_t svthip_me_hme_search_center_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
                                         const svthip_pa_picture *ref, const svthip_me_params *params,
                                         uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
                                         const uint32_t *d_l0_best_mv64, svthip_fullpel_desc *d_desc,
-                                        int16_t *d_center, void *stream);
+                                        int16_t *d_center, int16_t *d_hme_state, void *stream);
 
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/svtav1_hip.h"
+
 // LDS row pitch of the staged reference window.  192 B: >= 16*8 + 64 (widest lane footprint at
 // search_area_width 127) and == 48 dwords, which puts rows y, y+3, y+5, y+6 (one ds_read_b128 lane
 // group) on four distinct bank quarters.
@@ -19,6 +21,11 @@ __global__ void fullpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t
                                  const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                  const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
                                  uint32_t* __restrict__ out_mv);
+
+__global__ void hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_picture cur, svthip_pa_picture ref,
+                                  svthip_me_params P, uint32_t list_index, const svthip_sb_origin* __restrict__ sbs,
+                                  const uint32_t* __restrict__ l0_best_mv64, svthip_fullpel_desc* __restrict__ out_desc,
+                                  int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 

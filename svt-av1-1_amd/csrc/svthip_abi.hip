@@ -136,6 +136,35 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
                           max_search_area_height, d_best_sad, d_best_mv, s);
 }
 
+int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                        const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
+                                        const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,
+                                        svthip_fullpel_desc* d_desc, int16_t* d_center, int16_t* d_hme_state, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (!d_pool || !cur || !ref || !params || !d_sb || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (list_index > 1) return fail(SVTHIP_ERR_BAD_PARAMETER, "list_index must be 0 or 1%s", "");
+    if (list_index == 1 && !d_l0_best_mv64 && params->temporal_layer_index > 0)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "list 1 needs the list-0 64x64 MVs (hme_mv_center_check direct candidate)%s", "");
+    const svthip_me_params& P = *params;
+    if (P.number_hme_search_region_in_width < 1 || P.number_hme_search_region_in_width > 2 ||
+        P.number_hme_search_region_in_height < 1 || P.number_hme_search_region_in_height > 2)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "HME search regions must be 1..2 per axis%s", "");
+    if ((cur->width & 7) || (cur->height & 7) || cur->width != ref->width || cur->height != ref->height)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be equal multiples of 8%s", "");
+    if ((cur->full_stride & 3u) || (ref->full_stride & 3u) || (cur->full_offset & 3))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "full-resolution strides / current-plane offset must be multiples of 4%s", "");
+    const int64_t max_off = (cur->full_offset > ref->full_offset ? cur->full_offset : ref->full_offset) +
+                            (int64_t)(cur->height + 136) * (cur->full_stride > ref->full_stride ? cur->full_stride : ref->full_stride);
+    if (max_off > 0x7fffffffLL) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture pool offsets must fit 31 bits%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb), dim3(256), 0, s, d_pool, *cur, *ref, P, list_index, d_sb,
+                       d_l0_best_mv64, d_desc, d_center, d_hme_state);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size_t src_plane_bytes, uint32_t src_stride,
                                  const uint8_t* ref_plane, size_t ref_plane_bytes, uint32_t ref_stride,
                                  const svthip_fullpel_desc* desc, uint32_t n_sb, uint32_t* best_sad, uint32_t* best_mv)

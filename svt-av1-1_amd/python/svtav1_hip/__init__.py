@@ -63,6 +63,10 @@ def lib() -> C.CDLL:
     L.svthip_me_fullpel_search_time_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                                     C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                                     C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    L.svthip_me_hme_search_center_dev.restype = C.c_int32
+    L.svthip_me_hme_search_center_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                  C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]
     _lib = L
     return L
 
@@ -128,6 +132,16 @@ class Context:
         _check(lib().svthip_me_fullpel_search_time_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb,
                                                        max_sw, max_sh, d_sad, d_mv, iters, C.byref(ms)))
         return ms.value
+
+
+def _hme_search_center_dev(self, d_pool, cur, ref, params, list_index, d_sb, n_sb, d_l0_mv64, d_desc, d_center=None,
+                           d_state=None, stream=None):
+    """cur/ref: PaPictureDesc, params: MeParams (host structs); the rest are device addresses."""
+    _check(lib().svthip_me_hme_search_center_dev(self._h, d_pool, C.byref(cur), C.byref(ref), C.byref(params), list_index,
+                                                 d_sb, n_sb, d_l0_mv64, d_desc, d_center, d_state, stream))
+
+
+Context.hme_search_center_dev = _hme_search_center_dev
 
 
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
