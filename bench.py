@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 
 W, H = 1920, 1080
 PICTURES_PER_STEP = 12
+HME_STREAMS = 6
 SEARCH_W = SEARCH_H = 64
 ALGO_BYTES_PER_BLOCK = 4096 + 127 * 127 + 680  # src + ref window + results = 20905 B
 ABSDIFF_PER_BLOCK = SEARCH_W * SEARCH_H * 2048  # 64 8x8 SADs x 32 abs-diffs per position
@@ -35,22 +36,23 @@ VALU_PEAK_ABSDIFF_PER_S = 256 * 4 * 64 * 16 / 16.15 * 2.4e9
 
 
 def build_pool(n_pictures, rank_seed):
-    """A picture pool: n_pictures+1 padded 1080p luma planes stacked in one buffer (picture i is
-    searched in picture i+1's predecessor), plus the per-SB descriptors with pool-relative offsets."""
+    """A picture pool: n_pictures+1 synthetic 1080p pictures (padded full-res + 1/4 + 1/16 planes each) stacked
+    in one buffer; picture i+1 is searched in picture i.  Also returns zero-centred full-pel descriptors (used
+    by the CPU baseline and by --no-hme)."""
     import svtav1_hip
     from svtav1_hip import synth
 
     pics = [synth.PaPicture(synth.synth_luma(W, H, t, seed=synth.SEED + 1000 * rank_seed)) for t in range(n_pictures + 1)]
-    plane_bytes = pics[0].full.size
-    pool = np.concatenate([p.full.reshape(-1) for p in pics])
+    pool, pdesc = svtav1_hip.build_picture_pool(pics)
+    pool = np.concatenate([pool, np.zeros(64, np.uint8)])
     descs = []
     for i in range(n_pictures):
         d = svtav1_hip.make_fullpel_desc(pics[i + 1], pics[i], None, SEARCH_W, SEARCH_H).astype(np.int64)
-        d[:, 0] += (i + 1) * plane_bytes  # current picture
-        d[:, 1] += i * plane_bytes  # its reference
+        d[:, 0] += pdesc[i + 1].full_offset  # current picture
+        d[:, 1] += pdesc[i].full_offset  # its reference
         descs.append(d)
     desc = np.concatenate(descs).astype(np.int32)
-    return pool, pics[0].stride, desc, pics
+    return pool, pics[0].stride, desc, pdesc
 
 
 def cpu_baseline(pool, stride, desc, seconds=12.0):
@@ -113,6 +115,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
     args = ap.parse_args()
 
     import torch
@@ -130,20 +133,44 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
-    pool, stride, desc, _ = build_pool(PICTURES_PER_STEP, rank)
+    pool, stride, desc, pdesc = build_pool(PICTURES_PER_STEP, rank)
     n_blocks = desc.shape[0]
+    n_sb = n_blocks // PICTURES_PER_STEP
     d_pool = torch.from_numpy(pool).to(dev)
-    d_desc = torch.from_numpy(desc).to(dev)
+    d_desc = torch.from_numpy(desc).to(dev)  # zero-centred windows; overwritten by the HME kernel each step
     d_sad = torch.empty((n_blocks, 85), dtype=torch.int32, device=dev)
     d_mv = torch.empty((n_blocks, 85), dtype=torch.int32, device=dev)
+    d_sb = torch.from_numpy(svtav1_hip.sb_origins(W, H).view(np.int16).copy()).to(dev)
+    params = svtav1_hip.default_me_params(W, H, 3, 0)
     ctx = svtav1_hip.Context(local_rank)
     a = (d_pool.data_ptr(), stride, d_pool.data_ptr(), stride, d_desc.data_ptr(), n_blocks, SEARCH_W, SEARCH_H,
          d_sad.data_ptr(), d_mv.data_ptr())
+    # One context (stream) per ME worker, like the reference's per-thread MeContext_t: the per-picture
+    # search-centre launches are small (510 workgroups) and overlap across streams.
+    workers = [svtav1_hip.Context(local_rank) for _ in range(HME_STREAMS)]
+    w_streams = [torch.cuda.ExternalStream(w.stream, device=dev) for w in workers]
+    main_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    done = [torch.cuda.Event() for _ in workers]
+    start = torch.cuda.Event()
 
     def step():
+        # hierarchical ME of every picture of the batch: search-centre kernel per picture (its descriptors land
+        # in the shared array), then ONE full-pel launch over all 510*P superblocks
+        if not args.no_hme:
+            start.record(main_stream)
+            for k, w in enumerate(workers):
+                w_streams[k].wait_event(start)  # previous step's full-pel launch has consumed d_desc
+            for i in range(PICTURES_PER_STEP):
+                workers[i % HME_STREAMS].hme_search_center_dev(d_pool.data_ptr(), pdesc[i + 1], pdesc[i], params, 0,
+                                                               d_sb.data_ptr(), n_sb, None, d_desc.data_ptr() + i * n_sb * 24)
+            for k, w in enumerate(workers):
+                done[k].record(w_streams[k])
+                main_stream.wait_event(done[k])
         ctx.fullpel_search_dev(*a)
 
     def sync():
+        for w in workers:
+            w.synchronize()
         ctx.synchronize()
         torch.cuda.synchronize()
 
@@ -187,7 +214,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 64x64 full-pel SAD search, 85 square PUs, 1080p 8-bit, one reference list",
+            "config": {"workload": "configs[1]: 64x64 full-pel SAD hierarchical ME (centre check + HME L0/L1/L2 + 64x64-area "
+                                   "full-pel search of 85 square PUs), 1080p 8-bit, one reference list"
+                       if not args.no_hme else "64x64 full-pel SAD search only (no HME), 85 square PUs, 1080p 8-bit",
                        "pictures_per_step_per_gpu": PICTURES_PER_STEP, "blocks_per_step_per_gpu": n_blocks,
                        "search_area": [SEARCH_W, SEARCH_H], "sharding": "pictures across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -203,6 +232,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pool, stride, desc)
         print(json.dumps(out), flush=True)
+    for w in workers:
+        w.close()
     ctx.close()
     if distributed:
         dist.destroy_process_group()

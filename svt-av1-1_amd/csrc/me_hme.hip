@@ -22,11 +22,25 @@ namespace svthip {
 
 namespace {
 
+// Unaligned 4-byte read as two ALIGNED dword loads + v_alignbyte.  A single misaligned global_load_dword is
+// legal on gfx950 but was measured ~10x slower here (the 64 lanes of a wave are split into per-lane requests);
+// aligned neighbours coalesce into full-rate requests.
 __device__ __forceinline__ uint32_t ldu32(const uint8_t* p)
 {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);  // one global_load_dword; gfx950 global memory handles any byte alignment
-    return v;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3u);
+    const uint32_t lo = q[0];
+    const uint32_t hi = sh ? q[1] : 0u;
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+// branch-free variant for bulk copies: always reads both aligned dwords (up to 7 bytes past p: pool slack)
+__device__ __forceinline__ uint32_t ldu32_nb(const uint8_t* p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u));
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
@@ -69,16 +83,16 @@ __device__ uint32_t wave_block_sad(const uint8_t* src, uint32_t src_stride, cons
     return wave_sum_u32(acc);
 }
 
-// SadLoopKernel by one wave: returns best SAD (not doubled) and position; strict '<' raster order.
-__device__ void wave_sad_loop(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride,
-                              uint32_t H, uint32_t W, uint32_t ref_stride_raw, int sw, int sh, int lane,
-                              uint32_t* best_sad, int* bx, int* by)
+// Generic SadLoopKernel by one wave straight from global memory (any block shape; used for partial SBs).
+__device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride,
+                                      uint32_t H, uint32_t W, uint32_t ref_stride_raw, int sw, int sh, int lane,
+                                      uint32_t* best_sad, int* bx, int* by)
 {
+    const int npos = sw * sh;
+    unsigned long long best = ~0ull;
     const uint32_t ndw = (W + 3) >> 2;
     const uint32_t tail = W & 3u;
     const uint32_t tailmask = tail ? ((1u << (8 * tail)) - 1u) : 0xffffffffu;
-    const int npos = sw * sh;
-    unsigned long long best = ~0ull;
     for (int pos = lane; pos < npos; pos += 64) {
         const int y = pos / sw, x = pos - y * sw;
         const uint8_t* r0 = ref + (size_t)y * ref_stride_raw + x;
@@ -98,6 +112,145 @@ __device__ void wave_sad_loop(const uint8_t* src, uint32_t src_stride, const uin
         }
         const unsigned long long key = ((unsigned long long)acc << 32) | (uint32_t)pos;
         best = key < best ? key : best;  // a lane visits its positions in raster order
+    }
+    best = wave_min_u64(best);
+    const uint32_t pos = (uint32_t)best;
+    *best_sad = (uint32_t)(best >> 32);
+    *by = (int)(pos / (uint32_t)sw);
+    *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
+}
+
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// SadLoopKernel by one wave for the full-SB block shapes (W = 16 / 32 / 64 px, H rows taken every second plane
+// row), LDS-staged:
+//   * the W x H source block and a band of the search window are copied to this wave's LDS slice with aligned,
+//     coalesced dword loads (the window is re-aligned with v_alignbyte so search column 0 sits on a dword);
+//   * an item is 8 horizontally consecutive search positions of one search row; its lanes read W/4 + 2 window
+//     dwords per block row and issue 2 * W/4 v_qsad_pk_u16_u8 (4 positions x 4 pixels each);
+//   * when a level has fewer than 64 items (HME L1 / L2), RP lanes share an item and split its block rows;
+//   * best position: 64-bit key (sad << 32 | raster index), lane-local strict min, then a wave min.
+// `lds` is this wave's private slice of `lds_bytes` bytes; the search area is processed in bands of rows that fit.
+template <int W>
+__device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride_raw,
+                                  int H, int sw, int sh, int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad,
+                                  int* bx, int* by)
+{
+    constexpr int WD = W / 4;                 // source dwords per block row
+    constexpr int FLUSH = (W == 16) ? 16 : (W == 32 ? 8 : 4);  // rows a u16 accumulator can take: rows*W*255 < 65536
+    uint32_t* srcbuf = reinterpret_cast<uint32_t*>(lds);       // [H][WD]
+    const int noct = (sw + 7) >> 3;
+    const int pitch = 2 * noct + WD + 1;      // window dwords per row (+1: odd pitch spreads rows over banks)
+    uint32_t* win = srcbuf + H * WD;
+    const int avail_rows = (lds_bytes / 4 - H * WD) / pitch;
+    int band = avail_rows - (2 * H - 2);      // search rows per band
+    if (band > sh) band = sh;
+    if (band < 1) {  // window row wider than the slice (cannot happen for the reference's parameter ranges)
+        wave_sad_loop_generic(src, src_stride, ref, ref_stride_raw * 2, (uint32_t)H, (uint32_t)W, ref_stride_raw, sw, sh, lane,
+                              best_sad, bx, by);
+        return;
+    }
+
+    // source block -> LDS (rows are src_stride apart, already the doubled stride); 4 dwords per lane in flight
+    for (int i0 = 0; i0 < H * WD; i0 += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = min(i0 + k * 64 + lane, H * WD - 1);  // clamped: no branches, loads stay in flight together
+            const int r = i / WD, c = i - r * WD;                // WD is a power of two: shifts
+            v[k] = ldu32_nb(src + (uint32_t)r * src_stride + 4u * (uint32_t)c);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) srcbuf[min(i0 + k * 64 + lane, H * WD - 1)] = v[k];
+    }
+
+    // items and row-parts
+    const int items_row = noct;
+    unsigned long long best = ~0ull;
+
+    for (int y0 = 0; y0 < sh; y0 += band) {
+        const int bh = min(band, sh - y0);
+        const int wrows = bh + 2 * H - 2;
+        // stage window rows y0 .. y0+wrows-1 (plane rows), pitch dwords each
+        {
+            // every lane has 8 independent (aligned-pair) loads in flight: the copy is latency-bound otherwise
+            const uint8_t* base = ref + (size_t)y0 * ref_stride_raw;
+            const int total = wrows * pitch;
+            const uint32_t inv_pitch = (1u << 20) / (uint32_t)pitch + 1u;  // i / pitch == (i * inv) >> 20 for i < 2^20 / pitch
+            for (int i0 = 0; i0 < total; i0 += 512) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = min(i0 + k * 64 + lane, total - 1);  // clamped, branch-free
+                    const int r = (int)(((uint32_t)i * inv_pitch) >> 20), c = i - r * pitch;
+                    v[k] = ldu32_nb(base + (uint32_t)r * ref_stride_raw + 4u * (uint32_t)c);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) win[min(i0 + k * 64 + lane, total - 1)] = v[k];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+        const int nitems = items_row * bh;
+        int RP = 1;
+        while (RP < 8 && nitems * RP * 2 <= 64 && RP * 2 <= H) RP <<= 1;
+        const int ipw = 64 / RP;              // items per wave pass
+        const int part = lane & (RP - 1);
+        const uint32_t inv_items = (1u << 20) / (uint32_t)items_row + 1u;
+        for (int it0 = 0; it0 < nitems; it0 += ipw) {
+            const int item = it0 + (lane / RP);
+            const bool valid = item < nitems;
+            const int iy = valid ? (int)(((uint32_t)item * inv_items) >> 20) : 0;
+            const int io = valid ? item - iy * items_row : 0;
+            uint32_t sad[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) sad[j] = 0;
+            uint64_t acc0 = 0, acc1 = 0;
+            int since = 0;
+            for (int r = part; r < H; r += RP) {
+                const uint32_t* wr = win + (iy + 2 * r) * pitch + 2 * io;
+                const uint32_t* sr = srcbuf + r * WD;
+                uint32_t d[WD + 2];
+#pragma unroll
+                for (int c = 0; c < WD + 2; c++) d[c] = wr[c];
+#pragma unroll
+                for (int c = 0; c < WD; c++) {
+                    const uint32_t sv = sr[c];
+                    acc0 = __builtin_amdgcn_qsad_pk_u16_u8(pack64(d[c], d[c + 1]), sv, acc0);
+                    acc1 = __builtin_amdgcn_qsad_pk_u16_u8(pack64(d[c + 1], d[c + 2]), sv, acc1);
+                }
+                if (++since == FLUSH) {
+                    since = 0;
+                    sad[0] += (uint32_t)acc0 & 0xffffu; sad[1] += ((uint32_t)acc0) >> 16;
+                    sad[2] += (uint32_t)(acc0 >> 32) & 0xffffu; sad[3] += (uint32_t)(acc0 >> 48);
+                    sad[4] += (uint32_t)acc1 & 0xffffu; sad[5] += ((uint32_t)acc1) >> 16;
+                    sad[6] += (uint32_t)(acc1 >> 32) & 0xffffu; sad[7] += (uint32_t)(acc1 >> 48);
+                    acc0 = acc1 = 0;
+                }
+            }
+            sad[0] += (uint32_t)acc0 & 0xffffu; sad[1] += ((uint32_t)acc0) >> 16;
+            sad[2] += (uint32_t)(acc0 >> 32) & 0xffffu; sad[3] += (uint32_t)(acc0 >> 48);
+            sad[4] += (uint32_t)acc1 & 0xffffu; sad[5] += ((uint32_t)acc1) >> 16;
+            sad[6] += (uint32_t)(acc1 >> 32) & 0xffffu; sad[7] += (uint32_t)(acc1 >> 48);
+            // sum the row-parts of an item (its RP lanes are consecutive)
+            for (int m = 1; m < RP; m <<= 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) sad[j] += __shfl_xor(sad[j], m);
+            }
+            if (valid && part == 0) {
+                const int ys = y0 + iy;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int xs = 8 * io + j;
+                    if (xs < sw) {
+                        const unsigned long long key = ((unsigned long long)sad[j] << 32) | (uint32_t)(ys * sw + xs);
+                        best = key < best ? key : best;  // raster order within the lane: strict '<' keeps the first
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     best = wave_min_u64(best);
     const uint32_t pos = (uint32_t)best;
@@ -136,6 +289,8 @@ __device__ __forceinline__ int round_hme_width(int w)
     return (w < 8) ? 8 : ((w & 7) ? (w + (w - ((w >> 3) << 3))) : w);  // :4528 (adds the remainder, sic)
 }
 
+constexpr int kHmeLdsPerWave = 12 * 1024;  // per-wave LDS slice: source block + a band of the search window
+
 struct HmeShared {
     unsigned long long cost[8];   // centre-check candidate costs
     int rx[3][4], ry[3][4];       // per level, per region ([w][h] flattened as w*2+h) centres
@@ -153,8 +308,10 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                                                          int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state)
 {
     __shared__ HmeShared sh;
+    __shared__ __attribute__((aligned(16))) uint8_t hme_lds[4 * kHmeLdsPerWave];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint8_t* wlds = hme_lds + wave * kHmeLdsPerWave;
     const uint32_t sbi = blockIdx.x;
     const int ox = sbs[sbi].x, oy = sbs[sbi].y;
     const int pw = cur.width, ph = cur.height;
@@ -225,8 +382,12 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                     const uint8_t* s = pool + cur.sixteenth_offset + (size_t)(16 + o_y) * cur.sixteenth_stride + 16 + o_x;
                     const uint8_t* r = pool + ref.sixteenth_offset + (size_t)(16 + o_y + yo) * ref.sixteenth_stride + 16 + o_x + xo;
                     int bx, by;
-                    wave_sad_loop(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride * 2, (sb_h >> 2) >> 1, sb_w >> 2,
-                                  ref.sixteenth_stride, sw, shh, lane, &sad0, &bx, &by);
+                    if (sb_w == 64)
+                        wave_sad_loop_lds<16>(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride, 8, sw, shh, lane, wlds,
+                                              kHmeLdsPerWave, &sad0, &bx, &by);
+                    else
+                        wave_sad_loop_generic(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride * 2, (sb_h >> 2) >> 1, sb_w >> 2,
+                                              ref.sixteenth_stride, sw, shh, lane, &sad0, &bx, &by);
                     x0 = s16(s16(bx + xo) * 4);
                     y0 = s16(s16(by + yo) * 4);
                 }
@@ -239,8 +400,12 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                     const uint8_t* s = pool + cur.quarter_offset + (size_t)(32 + o_y) * cur.quarter_stride + 32 + o_x;
                     const uint8_t* r = pool + ref.quarter_offset + (size_t)(32 + o_y + yo) * ref.quarter_stride + 32 + o_x + xo;
                     int bx, by;
-                    wave_sad_loop(s, cur.quarter_stride * 2, r, ref.quarter_stride * 2, (sb_h >> 1) >> 1, sb_w >> 1,
-                                  ref.quarter_stride, sw, shh, lane, &sad1, &bx, &by);
+                    if (sb_w == 64)
+                        wave_sad_loop_lds<32>(s, cur.quarter_stride * 2, r, ref.quarter_stride, 16, sw, shh, lane, wlds,
+                                              kHmeLdsPerWave, &sad1, &bx, &by);
+                    else
+                        wave_sad_loop_generic(s, cur.quarter_stride * 2, r, ref.quarter_stride * 2, (sb_h >> 1) >> 1, sb_w >> 1,
+                                              ref.quarter_stride, sw, shh, lane, &sad1, &bx, &by);
                     x1 = s16(s16(bx + xo) * 2);
                     y1 = s16(s16(by + yo) * 2);
                 }
@@ -251,8 +416,12 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                     clip_window(xo, yo, sw, shh, ox, oy, 63, 63, ref.width, ref.height);
                     const uint8_t* r = ref_full + (size_t)(oy + yo) * ref.full_stride + ox + xo;
                     int bx, by;
-                    wave_sad_loop(src, cur.full_stride * 2, r, ref.full_stride * 2, sb_h >> 1, sb_w, ref.full_stride, sw, shh,
-                                  lane, &sad2, &bx, &by);
+                    if (sb_w == 64)
+                        wave_sad_loop_lds<64>(src, cur.full_stride * 2, r, ref.full_stride, 32, sw, shh, lane, wlds,
+                                              kHmeLdsPerWave, &sad2, &bx, &by);
+                    else
+                        wave_sad_loop_generic(src, cur.full_stride * 2, r, ref.full_stride * 2, sb_h >> 1, sb_w, ref.full_stride, sw,
+                                              shh, lane, &sad2, &bx, &by);
                     x2 = s16(bx + xo);
                     y2 = s16(by + yo);
                 }
