@@ -79,6 +79,40 @@ class Oracle:
           desc.ctypes.data, center.ctypes.data, hme_state.ctypes.data if hme_state is not None else None)
         return desc, center
 
+    def interp_planes(self, ref_plane, ref_off, x0, y0, w, h):
+        """b/h/j tiles (h x w) whose (0,0) is search-region coordinate (x0,y0); search position (0,0) = ref_plane.flat[ref_off]."""
+        b = np.zeros((h, w), np.uint8); hh = np.zeros((h, w), np.uint8); j = np.zeros((h, w), np.uint8)
+        f = self.lib.orc_interp_planes
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f(ref_plane.ctypes.data + ref_off, ref_plane.shape[1], x0, y0, w, h, b.ctypes.data, hh.ctypes.data, j.ctypes.data)
+        return b, hh, j
+
+    def ssd_wrapped(self, a, b):
+        f = self.lib.orc_ssd_wrapped
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        return f(a.ctypes.data, a.shape[1], b.ctypes.data, b.shape[1], a.shape[1], a.shape[0])
+
+    def subpel_refine_batch(self, src_plane, ref_plane, desc, sad, mv, disable_8x8=False, src_stride=None, ref_stride=None):
+        """In: full-pel (sad, mv) [n,85]; out: refined copies + (ssd [n,85], dir [n,85])."""
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n = desc.shape[0]
+        sad = np.ascontiguousarray(sad, dtype=np.uint32).copy()
+        mv = np.ascontiguousarray(mv, dtype=np.uint32).copy()
+        ssd = np.zeros((n, 85), np.uint32)
+        dr = np.zeros((n, 85), np.uint8)
+        f = self.lib.orc_subpel_refine_batch
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_void_p]
+        ss = src_stride if src_stride is not None else src_plane.shape[1]
+        rs = ref_stride if ref_stride is not None else ref_plane.shape[1]
+        f(src_plane.ctypes.data, ss, ref_plane.ctypes.data, rs, desc.ctypes.data, n, int(disable_8x8), sad.ctypes.data,
+          mv.ctypes.data, ssd.ctypes.data, dr.ctypes.data)
+        return sad, mv, ssd, dr
+
     def sad_loop(self, src, src_off, src_stride, ref, ref_off, ref_stride, height, width, ref_stride_raw, sw, sh):
         best = C.c_uint64(0)
         x = C.c_int16(-12345)
@@ -146,6 +180,17 @@ class ReferenceME:
         self.lib.ref_me_lcu_run.restype = C.c_int
         self.lib.ref_me_lcu_run.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+
+    def interp_region(self, ref_plane, ref_off, sw, sh, rows, cols):
+        """The reference's InterpolateSearchRegionAVC on the region whose position (0,0) is ref_plane.flat[ref_off];
+        returns the consumed b/h/j planes cropped to rows x cols."""
+        f = self.lib.ref_interp_region
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        b = np.zeros((rows, cols), np.uint8); h = np.zeros((rows, cols), np.uint8); j = np.zeros((rows, cols), np.uint8)
+        rc = f(ref_plane.ctypes.data + ref_off, ref_plane.shape[1], sw, sh, rows, cols, b.ctypes.data, h.ctypes.data, j.ctypes.data)
+        assert rc == 0
+        return b, h, j
 
     def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0):
         """cur/ref0/ref1: svtav1_hip.synth.PaPicture; params: svtav1_hip.MeParams.

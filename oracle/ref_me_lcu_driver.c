@@ -187,3 +187,31 @@ int ref_me_lcu_run(uint8_t **planes, int width, int height, const int32_t *ip, u
         }
     return 0;
 }
+
+/* Runs the reference's InterpolateSearchRegionAVC (Codec/EbMotionEstimation.c:1707) on a search region whose
+ * position (0,0) is `ref00` and copies out the three planes as MotionEstimateLcu hands them to the refinement
+ * (:6923-6926): b from row 2, h from column 1, j from (0,0); out arrays are [rows][cols] with the context's stride
+ * cropped to `cols`.  Used to pin the plane geometry of oracle/svt_subpel_oracle.c. */
+int ref_interp_region(uint8_t *ref00, int stride, int sw, int sh, int rows, int cols, uint8_t *out_b, uint8_t *out_h,
+                      uint8_t *out_j)
+{
+    static EbMemoryMapEntry *mm = NULL;
+    static uint32_t mm_index;
+    static uint64_t mm_total;
+    if (!mm) mm = (EbMemoryMapEntry *)calloc(1 << 16, sizeof(EbMemoryMapEntry));
+    memoryMap = mm;
+    mm_index = 0;
+    memoryMapIndex = &mm_index;
+    totalLibMemory = &mm_total;
+    MeContext_t *ctx = NULL;
+    if (MeContextCtor(&ctx) != EB_ErrorNone) return -3;
+    InterpolateSearchRegionAVC(ctx, 0, ref00, (uint32_t)stride, (uint32_t)sw + 63, (uint32_t)sh + 63, 8, ASM_NON_AVX2);
+    const uint32_t is = ctx->interpolated_stride;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            out_b[y * cols + x] = ctx->pos_b_buffer[0][0][(2 + y) * is + x];
+            out_h[y * cols + x] = ctx->pos_h_buffer[0][0][y * is + 1 + x];
+            out_j[y * cols + x] = ctx->pos_j_buffer[0][0][y * is + x];
+        }
+    return 0;
+}

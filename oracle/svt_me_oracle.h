@@ -65,6 +65,21 @@ void orc_hme_search_center_batch(const uint8_t *pool, const svthip_pa_picture *c
                                  const uint32_t *l0_best_mv64, svthip_fullpel_desc *desc, int16_t *center_xy,
                                  int16_t *hme_state /* [n_sb][25], carried from list 0 to list 1; may be NULL */);
 
+/* ---- sub-pel (oracle/svt_subpel_oracle.c) ---- */
+/* b / h / j half-pel planes of InterpolateSearchRegionAVC as w x h tiles whose (0,0) is search-region coordinate (x0,y0):
+ * b[x,y] = half-pel (x-1/2, y), h[x,y] = (x, y-1/2), j[x,y] = (x-1/2, y-1/2) (vertical filter of the rounded b). */
+void orc_interp_planes(const uint8_t *ref00, uint32_t ref_stride, int x0, int y0, int w, int h, uint8_t *b, uint8_t *hh,
+                       uint8_t *j);
+/* SpatialFullDistortionKernel*_SSSE3_INTRIN semantics: sum of squared 8-bit WRAPPED differences */
+uint32_t orc_ssd_wrapped(const uint8_t *src, uint32_t src_stride, const uint8_t *rec, uint32_t rec_stride, uint32_t w, uint32_t h);
+/* half-pel + quarter-pel refinement of the 85 square PUs (SSD_SEARCH mode, M0/M1 flags) */
+void orc_subpel_refine_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                            int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                            uint32_t *best_mv, uint32_t *out_ssd, uint8_t *out_dir);
+void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
+                             const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv,
+                             uint32_t *out_ssd, uint8_t *out_dir);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,259 @@
+/*
+ * oracle/svt_subpel_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see svt_me_oracle.h).
+ *
+ * Plain-C restatement of the sub-pel half of MotionEstimateLcu (Source/Lib/Codec/EbMotionEstimation.c):
+ *   InterpolateSearchRegionAVC (:1707-1835)  -> the b / h / j half-pel planes as pure functions of the reference
+ *   HalfPelSearch_LCU / PU_HalfPelRefinement (:2246-2786 / :1842-2240), SSD_SEARCH mode
+ *   QuarterPelSearch_LCU / SetQuarterPelRefinementInputsOnTheFly / PU_QuarterPelRefinementOnTheFly /
+ *   CombinedAveragingSSD (:3337-4114 / :3246-3331 / :2824-3239 / :2792-2817)
+ *
+ * PINNING STATUS.  The leaf arithmetic is pinned against the reference's own kernels in oracle/_ref
+ * (AvcStyleLumaInterpolationFilter{Horizontal,Vertical}_SSSE3_INTRIN, SpatialFullDistortionKernel*_SSSE3_INTRIN,
+ * CombinedAveragingSAD) and the plane geometry against the reference's InterpolateSearchRegionAVC
+ * (tests/test_subpel_vs_ref.py).  The per-PU refinement CONTROL FLOW (PU_HalfPelRefinement and the quarter-pel
+ * functions) is restated from the source text only: the reference's sub-pel path calls Log2f_SSE2, which exists
+ * only in a NASM file this image cannot assemble, so it cannot be executed here -- "parity unpinned" for that
+ * control flow (DESIGN.md "oracle").
+ */
+#include "svt_me_oracle.h"
+
+static inline int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+/* 4-tap AVC-style half-pel filter {-2,18,18,-2}, +16 >> 5 (arithmetic), clip to u8
+ * (ASM_SSSE3/EbAvcStyleMcp_Intrinsic_SSSE3.c:200-246 horizontal, :318-370 vertical). */
+static inline int f4(int a, int b, int c, int d) { return clip8((-2 * a + 18 * b + 18 * c - 2 * d + 16) >> 5); }
+
+typedef struct {
+    const uint8_t *ref; /* reference sample at search position (0,0) */
+    int stride;
+} RefView;
+
+static inline int A_(const RefView *r, int x, int y) { return r->ref[y * r->stride + x]; }
+/* b[x,y]: half-pel between x-1 and x (pos_b consumed from row 2, :6923) */
+static inline int B_(const RefView *r, int x, int y) { return f4(A_(r, x - 2, y), A_(r, x - 1, y), A_(r, x, y), A_(r, x + 1, y)); }
+/* h[x,y]: half-pel between y-1 and y (pos_h consumed from column 1, :6925) */
+static inline int H_(const RefView *r, int x, int y) { return f4(A_(r, x, y - 2), A_(r, x, y - 1), A_(r, x, y), A_(r, x, y + 1)); }
+/* j[x,y]: vertical filter of the ROUNDED b plane (:1782-1791) */
+static inline int J_(const RefView *r, int x, int y) { return f4(B_(r, x, y - 2), B_(r, x, y - 1), B_(r, x, y), B_(r, x, y + 1)); }
+
+static inline int sample(const RefView *r, int plane, int x, int y)
+{
+    switch (plane) {
+    case 0: return A_(r, x, y);
+    case 1: return B_(r, x, y);
+    case 2: return H_(r, x, y);
+    default: return J_(r, x, y);
+    }
+}
+
+void orc_interp_planes(const uint8_t *ref00, uint32_t ref_stride, int x0, int y0, int w, int h, uint8_t *b, uint8_t *hh,
+                       uint8_t *j)
+{
+    RefView r = {ref00, (int)ref_stride};
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            b[y * w + x] = (uint8_t)B_(&r, x0 + x, y0 + y);
+            hh[y * w + x] = (uint8_t)H_(&r, x0 + x, y0 + y);
+            j[y * w + x] = (uint8_t)J_(&r, x0 + x, y0 + y);
+        }
+}
+
+/* SpatialFullDistortionKernel*_SSSE3_INTRIN: squared 8-bit WRAPPED difference, e = |int8(a - b)| with -128 -> 128
+ * (ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c:497-623). */
+static inline uint32_t wrap_sq(int a, int b)
+{
+    int d = (a - b) & 255;
+    int e = d > 128 ? 256 - d : d;
+    return (uint32_t)(e * e);
+}
+
+uint32_t orc_ssd_wrapped(const uint8_t *src, uint32_t src_stride, const uint8_t *rec, uint32_t rec_stride, uint32_t w, uint32_t h)
+{
+    uint32_t s = 0;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) s += wrap_sq(src[y * src_stride + x], rec[y * rec_stride + x]);
+    return s;
+}
+
+#define DIR_TL 0
+#define DIR_T 1
+#define DIR_TR 2
+#define DIR_R 3
+#define DIR_BR 4
+#define DIR_B 5
+#define DIR_BL 6
+#define DIR_L 7
+
+/* candidate order of PU_HalfPelRefinement: L, R, T, B, TL, TR, BR, BL  -> (plane, dx, dy, mvdx, mvdy) */
+static const int8_t kHalf[8][5] = {{1, 0, 0, -2, 0}, {1, 1, 0, 2, 0},  {2, 0, 0, 0, -2}, {2, 0, 1, 0, 2},
+                                   {3, 0, 0, -2, -2}, {3, 1, 0, 2, -2}, {3, 1, 1, 2, 2},  {3, 0, 1, -2, 2}};
+
+static void pu_half_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo,
+                        uint32_t *best_sad, uint32_t *best_mv, uint32_t *best_ssd, uint8_t *dir)
+{
+    const int16_t x_mv = (int16_t)(*best_mv & 0xffff), y_mv = (int16_t)(*best_mv >> 16);
+    const int xs = (x_mv >> 2) - xo, ys = (y_mv >> 2) - yo;
+    const uint8_t *s = src + py * src_stride + px;
+    uint32_t ssd = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) ssd += wrap_sq(s[y * src_stride + x], A_(r, xs + px + x, ys + py + y));
+    *best_ssd = ssd; /* :1912 */
+    uint64_t dist[8];
+    for (int k = 0; k < 8; k++) {
+        uint32_t d = 0, sad = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int p = sample(r, kHalf[k][0], xs + px + x + kHalf[k][1], ys + py + y + kHalf[k][2]);
+                const int sv = s[y * src_stride + x];
+                d += wrap_sq(sv, p);
+                sad += (uint32_t)(sv > p ? sv - p : p - sv);
+            }
+        dist[k] = d;
+        if (d < *best_ssd) { /* strict '<', :1942 */
+            *best_sad = sad;  /* true SAD over all rows, :1943 */
+            *best_mv = ((uint32_t)(uint16_t)(y_mv + kHalf[k][4]) << 16) | (uint16_t)(x_mv + kHalf[k][3]);
+            *best_ssd = d;
+        }
+    }
+    /* direction: first match in the order L, R, T, B, TL, TR, BL, BR (:2209-2238; note BL before BR) */
+    uint64_t m = dist[0];
+    for (int k = 1; k < 8; k++)
+        if (dist[k] < m) m = dist[k];
+    if (m == dist[0]) *dir = DIR_L;
+    else if (m == dist[1]) *dir = DIR_R;
+    else if (m == dist[2]) *dir = DIR_T;
+    else if (m == dist[3]) *dir = DIR_B;
+    else if (m == dist[4]) *dir = DIR_TL;
+    else if (m == dist[5]) *dir = DIR_TR;
+    else if (m == dist[7]) *dir = DIR_BL;
+    else *dir = DIR_BR;
+}
+
+/* SetQuarterPelRefinementInputsOnTheFly (:3271-3323): [method][position L,R,T,B,TL,TR,BR,BL][buf1/buf2][plane,dx,dy],
+ * plane 0 = integer (A), 1 = b, 2 = h, 3 = j */
+static const int8_t kQuarter[4][8][2][3] = {
+    /* EB_QUARTER_IN_FULL */
+    {{{1, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {1, 1, 0}}, {{2, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {2, 0, 1}},
+     {{1, 0, 0}, {2, 0, 0}}, {{2, 0, 0}, {1, 1, 0}}, {{2, 0, 1}, {1, 1, 0}}, {{1, 0, 0}, {2, 0, 1}}},
+    /* EB_QUARTER_IN_HALF_HORIZONTAL */
+    {{{0, -1, 0}, {1, 0, 0}}, {{1, 0, 0}, {0, 0, 0}}, {{3, 0, 0}, {1, 0, 0}}, {{1, 0, 0}, {3, 0, 1}},
+     {{2, -1, 0}, {1, 0, 0}}, {{1, 0, 0}, {2, 0, 0}}, {{1, 0, 0}, {2, 0, 1}}, {{2, -1, 1}, {1, 0, 0}}},
+    /* EB_QUARTER_IN_HALF_VERTICAL */
+    {{{3, 0, 0}, {2, 0, 0}}, {{2, 0, 0}, {3, 1, 0}}, {{0, 0, -1}, {2, 0, 0}}, {{2, 0, 0}, {0, 0, 0}},
+     {{1, 0, -1}, {2, 0, 0}}, {{2, 0, 0}, {1, 1, -1}}, {{2, 0, 0}, {1, 1, 0}}, {{1, 0, 0}, {2, 0, 0}}},
+    /* EB_QUARTER_IN_HALF_DIAGONAL */
+    {{{2, -1, 0}, {3, 0, 0}}, {{3, 0, 0}, {2, 0, 0}}, {{1, 0, -1}, {3, 0, 0}}, {{3, 0, 0}, {1, 0, 0}},
+     {{2, -1, 0}, {1, 0, -1}}, {{1, 0, -1}, {2, 0, 0}}, {{1, 0, 0}, {2, 0, 0}}, {{2, -1, 0}, {1, 0, 0}}}};
+
+static const int8_t kQmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
+
+static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo,
+                           uint32_t *best_sad, uint32_t *best_mv, uint32_t *best_ssd, uint8_t d)
+{
+    const int16_t x_mv = (int16_t)(*best_mv & 0xffff), y_mv = (int16_t)(*best_mv >> 16);
+    const int xs = ((x_mv + 2) >> 2) - xo, ys = ((y_mv + 2) >> 2) - yo; /* :2847-2848 */
+    const int method = (y_mv & 2) + ((x_mv & 2) >> 1);
+    int valid[8]; /* L, R, T, B, TL, TR, BR, BL */
+    if (method) { /* :2859-2869 */
+        valid[4] = (d == DIR_R || d == DIR_BR || d == DIR_B);
+        valid[2] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
+        valid[5] = (d == DIR_B || d == DIR_BL || d == DIR_L);
+        valid[1] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
+        valid[6] = (d == DIR_L || d == DIR_TL || d == DIR_T);
+        valid[3] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
+        valid[7] = (d == DIR_T || d == DIR_TR || d == DIR_R);
+        valid[0] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
+    } else { /* :2873-2880 */
+        valid[4] = (d == DIR_L || d == DIR_TL || d == DIR_T);
+        valid[2] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
+        valid[5] = (d == DIR_T || d == DIR_TR || d == DIR_R);
+        valid[1] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
+        valid[6] = (d == DIR_R || d == DIR_BR || d == DIR_B);
+        valid[3] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
+        valid[7] = (d == DIR_B || d == DIR_BL || d == DIR_L);
+        valid[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
+    }
+    const uint8_t *s = src + py * src_stride + px;
+    for (int k = 0; k < 8; k++) {
+        if (!valid[k]) continue;
+        const int8_t(*q)[3] = kQuarter[method][k];
+        uint32_t ssd = 0, sad = 0;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int p1 = sample(r, q[0][0], xs + px + x + q[0][1], ys + py + y + q[0][2]);
+                const int p2 = sample(r, q[1][0], xs + px + x + q[1][1], ys + py + y + q[1][2]);
+                const int avg = (p1 + p2 + 1) >> 1;
+                const int sv = s[y * src_stride + x];
+                const int e = sv - avg;
+                ssd += (uint32_t)(e * e); /* CombinedAveragingSSD: true SSD (:2792-2817) */
+                sad += (uint32_t)(e < 0 ? -e : e);
+            }
+        if (ssd < *best_ssd) {
+            *best_sad = sad;
+            *best_mv = ((uint32_t)(uint16_t)(y_mv + kQmv[k][1]) << 16) | (uint16_t)(x_mv + kQmv[k][0]);
+            *best_ssd = ssd;
+        }
+    }
+}
+
+static const uint8_t kTab16[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* Codec/EbMotionEstimation.h:89-94 */
+static const uint8_t kTab8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,  18, 19, 22, 23, 8,  9,  12, 13, 24, 25,
+                                  28, 29, 10, 11, 14, 15, 26, 27, 30, 31, 32, 33, 36, 37, 48, 49, 52, 53, 34, 35, 38, 39,
+                                  50, 51, 54, 55, 40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
+
+/* Sub-pel refinement of the 85 square PUs of one SB against one list (use_subpel_flag = 1, enc modes M0/M1:
+ * half-pel on every PU size, quarter-pel enabled, fractional_search64x64 = 1; :6857-6964).
+ *   src   : SB top-left in the padded source plane;  ref00: reference sample at search position (0,0)
+ *   best_*: [85] ME-buffer order, in/out;  out_ssd/out_dir: optional [85] (final SSD, half-pel direction)
+ *   disable_8x8: cu8x8_mode == CU_8x8_MODE_1 (8x8 PUs keep their full-pel result) */
+void orc_subpel_refine_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                            int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                            uint32_t *best_mv, uint32_t *out_ssd, uint8_t *out_dir)
+{
+    RefView r = {ref00, (int)ref_stride};
+    const int xo = x_search_area_origin, yo = y_search_area_origin, ss = (int)src_stride;
+    uint32_t ssd[85];
+    uint8_t dir[85];
+    for (int i = 0; i < 85; i++) { ssd[i] = 0; dir[i] = 0; }
+    /* HalfPelSearch_LCU order: 64x64, 32x32[0..3], 16x16[raster 0..15], 8x8[raster 0..63] */
+    pu_half_pel(src, ss, &r, 0, 0, 64, 64, xo, yo, &best_sad[0], &best_mv[0], &ssd[0], &dir[0]);
+    for (int p = 0; p < 4; p++)
+        pu_half_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], &dir[1 + p]);
+    for (int p = 0; p < 16; p++) {
+        const int i = 5 + kTab16[p];
+        pu_half_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
+    }
+    if (!disable_8x8)
+        for (int p = 0; p < 64; p++) {
+            const int i = 21 + kTab8[p];
+            pu_half_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
+        }
+    /* QuarterPelSearch_LCU: the 64x64 PU is refined with a 32x32 block at the SB origin (:3395-3409) */
+    pu_quarter_pel(src, ss, &r, 0, 0, 32, 32, xo, yo, &best_sad[0], &best_mv[0], &ssd[0], dir[0]);
+    for (int p = 0; p < 4; p++)
+        pu_quarter_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], dir[1 + p]);
+    for (int p = 0; p < 16; p++) {
+        const int i = 5 + kTab16[p];
+        pu_quarter_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
+    }
+    if (!disable_8x8)
+        for (int p = 0; p < 64; p++) {
+            const int i = 21 + kTab8[p];
+            pu_quarter_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
+        }
+    if (out_ssd)
+        for (int i = 0; i < 85; i++) out_ssd[i] = ssd[i];
+    if (out_dir)
+        for (int i = 0; i < 85; i++) out_dir[i] = dir[i];
+}
+
+void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
+                             const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv,
+                             uint32_t *out_ssd, uint8_t *out_dir)
+{
+    for (uint32_t i = 0; i < n_sb; i++) {
+        const int32_t *d = desc + 6 * i;
+        orc_subpel_refine_85pu(src_plane + d[0], src_stride, ref_plane + d[1], ref_stride, (int16_t)d[2], (int16_t)d[3], disable_8x8,
+                               best_sad + 85 * i, best_mv + 85 * i, out_ssd ? out_ssd + 85 * i : 0, out_dir ? out_dir + 85 * i : 0);
+    }
+}

@@ -1,0 +1,130 @@
+"""Pins the leaf arithmetic and plane geometry of the sub-pel oracle (oracle/svt_subpel_oracle.c) against the
+reference's own code in oracle/_ref: InterpolateSearchRegionAVC (b/h/j planes), the wrapped-SSD kernels and the
+averaging SAD.  The refinement control flow itself cannot be executed from the reference here (it calls a
+NASM-only symbol) and is covered by hand-computed invariants instead.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtav1_hip
+from svtav1_hip import synth
+
+
+@pytest.fixture(scope="module")
+def refme():
+    from oracle.binding import ReferenceME
+    if not ReferenceME.available():
+        pytest.skip("oracle/_ref/libsvtref_me.so not built")
+    return ReferenceME()
+
+
+@pytest.mark.parametrize("kind", ["synth", "random", "extreme"])
+@pytest.mark.parametrize("search", [(64, 64), (16, 9), (37, 21)])
+def test_half_pel_planes_match_reference_interpolation(oracle, refme, kind, search):
+    sw, sh = search
+    if kind == "synth":
+        img = synth.synth_luma(320, 256, 1)
+    elif kind == "random":
+        img = np.random.default_rng(3).integers(0, 256, (256, 320), dtype=np.uint8)
+    else:  # checkerboard of 0/255: exercises the clip on both sides
+        yy, xx = np.mgrid[0:256, 0:320]
+        img = (((xx // 3 + yy // 2) & 1) * 255).astype(np.uint8)
+    plane = synth.pad_plane(img, synth.PAD_FULL)
+    stride = plane.shape[1]
+    off = (synth.PAD_FULL + 70) * stride + synth.PAD_FULL + 90
+    rows, cols = sh + 63 + 1, sw + 63 + 1  # every sample the refinement can touch
+    rb, rh, rj = refme.interp_region(plane, off, sw, sh, rows, cols)
+    ob, oh, oj = oracle.interp_planes(plane, off, 0, 0, cols, rows)
+    assert np.array_equal(ob, rb), "b plane"
+    assert np.array_equal(oh, rh), "h plane"
+    assert np.array_equal(oj, rj), "j plane"
+
+
+def test_wrapped_ssd_matches_reference_kernels(oracle, reference):
+    rng = np.random.default_rng(8)
+    L = reference.lib
+    for name, w, h in (("SpatialFullDistortionKernel8x8_SSSE3_INTRIN", 8, 8), ("SpatialFullDistortionKernel16MxN_SSSE3_INTRIN", 16, 16),
+                       ("SpatialFullDistortionKernel16MxN_SSSE3_INTRIN", 32, 32), ("SpatialFullDistortionKernel16MxN_SSSE3_INTRIN", 64, 64)):
+        f = getattr(L, name)
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        for trial in range(10):
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            b = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            if trial == 0:
+                a[:] = 255; b[:] = 0      # |a-b| = 255 wraps to 1
+            if trial == 1:
+                a[:] = 200; b[:] = 72     # difference 128 stays 128
+            ref = f(a.ctypes.data, w, b.ctypes.data, w, w, h)
+            assert oracle.ssd_wrapped(a, b) == ref
+
+
+def test_averaging_sad_matches_reference(oracle, reference):
+    """(p1 + p2 + 1) >> 1 then SAD: the quarter-pel candidate metric's SAD side (CombinedAveragingSAD)."""
+    rng = np.random.default_rng(9)
+    f = reference.lib.CombinedAveragingSAD
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    for w in (8, 16, 32):
+        s = rng.integers(0, 256, (w, w), dtype=np.uint8)
+        a = rng.integers(0, 256, (w, w), dtype=np.uint8)
+        b = rng.integers(0, 256, (w, w), dtype=np.uint8)
+        ref = f(s.ctypes.data, w, a.ctypes.data, w, b.ctypes.data, w, w, w)
+        avg = ((a.astype(np.int32) + b + 1) >> 1)
+        assert int(np.abs(s.astype(np.int32) - avg).sum()) == ref
+
+
+def _setup(kind="synth"):
+    w, h = 256, 192
+    if kind == "synth":
+        cur = synth.PaPicture(synth.synth_luma(w, h, 1)); ref = synth.PaPicture(synth.synth_luma(w, h, 0))
+    else:
+        rng = np.random.default_rng(21)
+        base = rng.integers(0, 256, (h + 8, w + 8), dtype=np.uint8)
+        cur = synth.PaPicture(np.ascontiguousarray(base[4:4 + h, 4:4 + w])); ref = synth.PaPicture(np.ascontiguousarray(base[3:3 + h, 2:2 + w]))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    return cur, ref, desc
+
+
+def test_subpel_invariants(oracle):
+    """Properties the refinement must satisfy whatever the control flow: MVs move by at most 3 quarter-pels per
+    axis from the full-pel MV; a PU whose MV did not move keeps its full-pel SAD; the reported SSD never exceeds
+    the SSD at the full-pel position; identical pictures stay at their zero-distortion full-pel MV."""
+    cur, ref, desc = _setup()
+    s0, m0 = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    s1, m1, ssd, dr = oracle.subpel_refine_batch(cur.full, ref.full, desc, s0, m0)
+    x0 = (m0 & 0xffff).astype(np.int16).astype(np.int32); y0 = (m0 >> 16).astype(np.int16).astype(np.int32)
+    x1 = (m1 & 0xffff).astype(np.int16).astype(np.int32); y1 = (m1 >> 16).astype(np.int16).astype(np.int32)
+    assert (np.abs(x1 - x0) <= 3).all() and (np.abs(y1 - y0) <= 3).all()
+    same = (m1 == m0)
+    assert np.array_equal(s1[same], s0[same])
+    assert (dr <= 7).all()
+    sz, mz = oracle.fullpel_search_batch(cur.full, cur.full, desc)
+    s2, m2, ssd2, _ = oracle.subpel_refine_batch(cur.full, cur.full, desc, sz, mz)
+    assert np.array_equal(m2, mz) and (s2 == 0).all() and (ssd2 == 0).all()
+
+
+def test_subpel_finds_true_half_pel_shift(oracle):
+    """Reference picture = current picture shifted by exactly half a pixel horizontally (built with the same 4-tap
+    filter): the refined 64x64 MV must land on the half-pel position and its SSD must drop to ~0."""
+    w, h = 256, 192
+    yy, xx = np.mgrid[0:h + 16, 0:w + 16]
+    base = np.clip(128 + 60 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 40 * np.sin((xx + 2 * yy) / 23.0), 0, 255).astype(np.int32)
+    # cur(x) = half-pel sample of base between x+7 and x+8
+    a, b, c, d = base[8:8 + h, 6:6 + w], base[8:8 + h, 7:7 + w], base[8:8 + h, 8:8 + w], base[8:8 + h, 9:9 + w]
+    cur_img = np.clip((-2 * a + 18 * b + 18 * c - 2 * d + 16) >> 5, 0, 255).astype(np.uint8)
+    ref_img = base[8:8 + h, 8:8 + w].astype(np.uint8)
+    cur = synth.PaPicture(np.ascontiguousarray(cur_img)); ref = synth.PaPicture(np.ascontiguousarray(ref_img))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 16, 16)
+    inner = [i for i in range(desc.shape[0]) if desc[i, 4] == 16 and desc[i, 5] == 16 and desc[i, 2] == -8 and desc[i, 3] == -8]
+    s0, m0 = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    s1, m1, ssd, _ = oracle.subpel_refine_batch(cur.full, ref.full, desc, s0, m0)
+    nx = w // 64
+    inner = [i for i in inner if 0 < i % nx < nx - 1]  # SBs whose filter taps stay inside the picture
+    assert inner
+    for i in inner:
+        for pu in (0, 1, 2, 3, 4):
+            x = int(np.int16(m1[i, pu] & 0xffff)); y = int(np.int16(m1[i, pu] >> 16))
+            assert (x, y) == (-2, 0), f"SB {i} PU {pu}: MV ({x},{y}) instead of the half-pel position (-2,0)"
+            assert ssd[i, pu] == 0
