@@ -149,6 +149,23 @@ int32_t svthip_me_hme_search_center_dev(svthip_ctx *ctx, const uint8_t *d_pool, 
                                         const uint32_t *d_l0_best_mv64, svthip_fullpel_desc *d_desc,
                                         int16_t *d_center, int16_t *d_hme_state, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sub-pel refinement (half-pel then quarter-pel) of the 85 square PUs of a batch of superblocks, one list.
+ * Replaces InterpolateSearchRegionAVC + HalfPelSearch_LCU + QuarterPelSearch_LCU and the kernels behind them
+ * (Codec/EbMotionEstimation.c:1707-1835, :2246-2786, :3337-4114; AvcStyleLumaInterpolationFilter* in
+ * ASM_SSSE3/EbAvcStyleMcp_Intrinsic_SSSE3.c, SpatialFullDistortionKernel* in
+ * ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c, NxMSadAveragingKernel / CombinedAveragingSSD), in the
+ * configuration MotionEstimateLcu uses when use_subpel_flag = 1 at enc modes M0/M1 (:6857-6964): SSD_SEARCH
+ * metric, half-pel on every PU size incl. 64x64, quarter-pel on.
+ *
+ * d_desc is the SAME descriptor array the full-pel search consumed; d_best_sad / d_best_mv ([n_sb][85], ME-buffer
+ * order) hold the full-pel results on entry and the refined results on return (in place, like p_sb_best_sad/mv).
+ * disable_8x8_refinement = (cu8x8_mode == CU_8x8_MODE_1): 8x8 PUs keep their full-pel result. */
+int32_t svthip_me_subpel_refine_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                    const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
+                                    uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                    int32_t disable_8x8_refinement, uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

@@ -27,6 +27,11 @@ __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_pi
                                   const uint32_t* __restrict__ l0_best_mv64, svthip_fullpel_desc* __restrict__ out_desc,
                                   int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
+__global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
+                                int disable_8x8, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv);
+size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
+
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 
 }  // namespace svthip

@@ -136,6 +136,30 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
                           max_search_area_height, d_best_sad, d_best_mv, s);
 }
 
+int32_t svthip_me_subpel_refine_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                    uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb,
+                                    uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                    int32_t disable_8x8_refinement, uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (!d_src_plane || !d_ref_plane || !d_desc || !d_best_sad || !d_best_mv)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127%s", "");
+    if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
+    const size_t lds = svthip::subpel_lds_bytes(max_search_area_width, max_search_area_height);
+    if (lds > 160 * 1024) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel85_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
+                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, d_best_sad, d_best_mv);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                         const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
                                         const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,

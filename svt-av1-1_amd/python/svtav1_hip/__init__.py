@@ -67,6 +67,9 @@ def lib() -> C.CDLL:
     L.svthip_me_hme_search_center_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                                   C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]
+    L.svthip_me_subpel_refine_dev.restype = C.c_int32
+    L.svthip_me_subpel_refine_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -142,6 +145,15 @@ def _hme_search_center_dev(self, d_pool, cur, ref, params, list_index, d_sb, n_s
 
 
 Context.hme_search_center_dev = _hme_search_center_dev
+
+
+def _subpel_refine_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv, disable_8x8=False,
+                       stream=None):
+    _check(lib().svthip_me_subpel_refine_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh,
+                                             int(disable_8x8), d_sad, d_mv, stream))
+
+
+Context.subpel_refine_dev = _subpel_refine_dev
 
 
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
