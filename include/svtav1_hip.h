@@ -133,7 +133,8 @@ typedef struct svthip_sb_origin {
 } svthip_sb_origin;
 
 /* d_l0_best_mv64: for list_index 1, the final list-0 MV word of the 64x64 PU of every SB
- * (p_sb_best_mv[0][0][0], used by hme_mv_center_check :6076-6077); may be NULL for list 0.
+ * (p_sb_best_mv[0][0][0], used by hme_mv_center_check :6076-6077); may be NULL for list 0.  SB i's word is
+ * d_l0_best_mv64[i * l0_mv_stride] (stride 1 for a packed array, 85 when pointing at a [n_sb][85] MV array).
  * d_hme_state  : [n_sb][SVTHIP_HME_STATE_INT16] int16 scratch carried from the list-0 call to the list-1 call
  *                of the same SBs.  The reference keeps the per-region centre arrays (and the loop counters that
  *                guard their initialisation, :6325-6345) alive across its list loop, so list 1 starts from list 0's
@@ -146,7 +147,7 @@ typedef struct svthip_sb_origin {
 int32_t svthip_me_hme_search_center_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
                                         const svthip_pa_picture *ref, const svthip_me_params *params,
                                         uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
-                                        const uint32_t *d_l0_best_mv64, svthip_fullpel_desc *d_desc,
+                                        const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
                                         int16_t *d_center, int16_t *d_hme_state, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -165,6 +166,52 @@ int32_t svthip_me_subpel_refine_dev(svthip_ctx *ctx, const uint8_t *d_src_plane,
                                     const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
                                     uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
                                     int32_t disable_8x8_refinement, uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bi-prediction SAD + result packing for a batch of superblocks.
+ * Replaces the tail of MotionEstimateLcu (Codec/EbMotionEstimation.c:6973-7146): BiPredictionSearch /
+ * BiPredictionCompensation / BiPredAverging / SelectBuffer / QuarterPelCompensation (:5261-5342, :5090-5254,
+ * :4933-5081, :4762-4920) and the Sort3Elements-ordered fill of me_results[sb][pu] (:7047-7143).
+ *
+ * svthip_me_cu_result mirrors MeCuResults_t (Codec/EbMotionEstimationLcuResults.h:56-76) with the bit-fields
+ * widened: out[sb][pu], pu = 0..84 in RASTER order (0: 64x64, 1-4: 32x32, 5-20: 16x16 raster, 21-84: 8x8 raster),
+ * candidates sorted by distortion with '<=' ties favouring L0 then L1.  direction: 0 = UNI_PRED_LIST_0,
+ * 1 = UNI_PRED_LIST_1, 2 = BI_PRED.  For P pictures (n_lists = 1) the list-1 MV fields are written as 0 (the
+ * reference leaves whatever an earlier SB stored there).
+ * d_desc0 / d_desc1: the descriptor arrays of the two lists (search-area origins, plane offsets);
+ * d_sad*, d_mv*: final per-list results [n_sb][85] in ME-buffer order (after sub-pel refinement).
+ * bipred_8x8: cu8x8_mode == CU_8x8_MODE_0 (8x8 PUs get a bi-pred candidate as well, :7028). */
+typedef struct svthip_me_cu_result {
+    int16_t xMvL0, yMvL0, xMvL1, yMvL1;
+    uint32_t distortion[3];
+    uint8_t direction[3];
+    uint8_t totalMeCandidateIndex;
+} svthip_me_cu_result;
+
+int32_t svthip_me_bipred_pack_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                  const uint8_t *d_ref0_plane, uint32_t ref0_stride, const svthip_fullpel_desc *d_desc0,
+                                  const uint8_t *d_ref1_plane, uint32_t ref1_stride, const svthip_fullpel_desc *d_desc1,
+                                  uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                  const uint32_t *d_sad0, const uint32_t *d_mv0, const uint32_t *d_sad1, const uint32_t *d_mv1,
+                                  uint32_t n_lists, int32_t bipred_8x8, svthip_me_cu_result *d_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-picture motion estimation: the batched equivalent of the SB loop of MotionEstimationKernel calling
+ * MotionEstimateLcu (Codec/EbMotionEstimationProcess.c:478-556 -> Codec/EbMotionEstimation.c:6152-7162) for every SB
+ * in d_sb: per list { search-centre (HME) -> full-pel 85-PU search -> sub-pel refinement }, then bi-prediction and
+ * result packing.  This is the entry the ME process binds (one call per picture or per segment).
+ *   ref1 = NULL          : P picture (one list, numOfListToSearch = 0, :6271)
+ *   use_subpel_flag      : PictureParentControlSet_t::use_subpel_flag (:6857)
+ *   cu8x8_mode           : 0 = CU_8x8_MODE_0 (8x8 PUs are sub-pel refined and bi-predicted), 1 = CU_8x8_MODE_1
+ *   d_out                : [n_sb][85] svthip_me_cu_result, raster PU order (me_results[sb][pu])
+ *   d_list_sad/d_list_mv : optional [2][n_sb][85] copies of p_sb_best_sad / p_sb_best_mv (ME-buffer order); may be NULL
+ * All launches go to `stream` (NULL = context stream); the call does not synchronise.  Device scratch is owned by the
+ * context and grows on demand (allocation happens only when a larger batch than ever before is submitted). */
+int32_t svthip_motion_estimate_picture_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                           const svthip_pa_picture *ref0, const svthip_pa_picture *ref1,
+                                           const svthip_me_params *params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                           const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
+                                           uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
 
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */

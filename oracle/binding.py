@@ -113,6 +113,29 @@ class Oracle:
           mv.ctypes.data, ssd.ctypes.data, dr.ctypes.data)
         return sad, mv, ssd, dr
 
+    def bipred_pack_batch(self, src_plane, src_stride, ref0_plane, ref0_stride, desc0, sad0, mv0, ref1_plane=None,
+                          ref1_stride=0, desc1=None, sad1=None, mv1=None, bipred_8x8=True):
+        """-> structured array [n,85] of svtav1_hip.ME_CU_RESULT_DTYPE (raster PU order)."""
+        import svtav1_hip
+        n = desc0.shape[0]
+        n_lists = 2 if desc1 is not None else 1
+        out = np.zeros((n, 85), dtype=svtav1_hip.ME_CU_RESULT_DTYPE)
+        f = self.lib.orc_bipred_pack_batch
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        d0 = c(desc0, np.int32); s0 = c(sad0, np.uint32); m0 = c(mv0, np.uint32)
+        if n_lists == 2:
+            d1 = c(desc1, np.int32); s1 = c(sad1, np.uint32); m1 = c(mv1, np.uint32)
+            f(src_plane.ctypes.data, src_stride, ref0_plane.ctypes.data, ref0_stride, d0.ctypes.data, ref1_plane.ctypes.data,
+              ref1_stride, d1.ctypes.data, n, s0.ctypes.data, m0.ctypes.data, s1.ctypes.data, m1.ctypes.data, 2, int(bipred_8x8),
+              out.ctypes.data)
+        else:
+            f(src_plane.ctypes.data, src_stride, ref0_plane.ctypes.data, ref0_stride, d0.ctypes.data, None, 0, None, n,
+              s0.ctypes.data, m0.ctypes.data, None, None, 1, int(bipred_8x8), out.ctypes.data)
+        return out
+
     def sad_loop(self, src, src_off, src_stride, ref, ref_off, ref_stride, height, width, ref_stride_raw, sw, sh):
         best = C.c_uint64(0)
         x = C.c_int16(-12345)

@@ -80,6 +80,16 @@ void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, cons
                              const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv,
                              uint32_t *out_ssd, uint8_t *out_dir);
 
+/* bi-prediction SAD + Sort3Elements packing of the 85 PUs into raster-ordered results */
+void orc_bipred_pack_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref0_00, uint32_t ref0_stride, int16_t xo0,
+                          int16_t yo0, const uint8_t *ref1_00, uint32_t ref1_stride, int16_t xo1, int16_t yo1,
+                          const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1, int n_lists,
+                          int bipred_8x8, svthip_me_cu_result *out);
+void orc_bipred_pack_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref0_plane, uint32_t ref0_stride,
+                           const int32_t *desc0, const uint8_t *ref1_plane, uint32_t ref1_stride, const int32_t *desc1,
+                           uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
+                           int n_lists, int bipred_8x8, svthip_me_cu_result *out);
+
 #ifdef __cplusplus
 }
 #endif

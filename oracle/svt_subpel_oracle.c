@@ -257,3 +257,127 @@ void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, cons
                                best_sad + 85 * i, best_mv + 85 * i, out_ssd ? out_ssd + 85 * i : 0, out_dir ? out_dir + 85 * i : 0);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bi-prediction SAD and result packing (Codec/EbMotionEstimation.c:6973-7146, BiPredictionSearch :5261-5342,
+ * BiPredictionCompensation :5090-5254, BiPredAverging :4933-5081, SelectBuffer :4762-4815,
+ * QuarterPelCompensation :4818-4920, Sort3Elements :5434-5463).
+ *
+ * Pinned against the reference's own MotionEstimateLcu for integer MVs (sub-pel disabled) in
+ * tests/test_hme_vs_ref.py; the fractional-position buffer selection below is restated from the source only.
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* prediction sample of one list at fractional position `frac` = (x_mv & 3) + ((y_mv & 3) << 2), integer position (x,y)
+ * in search-region coordinates: F = A(x,y), Bq = b(x+1,y), Hq = h(x,y+1), Jq = j(x+1,y+1) are what BiPredictionCompensation's
+ * buffer indices select (:5155-5158). */
+static inline int bipred_sample(const RefView *r, int frac, int x, int y)
+{
+#define AV(a, b) (((a) + (b) + 1) >> 1)
+    switch (frac) {
+    case 0: return A_(r, x, y);
+    case 2: return B_(r, x + 1, y);
+    case 8: return H_(r, x, y + 1);
+    case 10: return J_(r, x + 1, y + 1);
+    case 1: return AV(A_(r, x, y), B_(r, x + 1, y));                 /* a */
+    case 3: return AV(B_(r, x + 1, y), A_(r, x + 1, y));             /* c */
+    case 4: return AV(A_(r, x, y), H_(r, x, y + 1));                 /* d */
+    case 5: return AV(B_(r, x + 1, y), H_(r, x, y + 1));             /* e */
+    case 6: return AV(B_(r, x + 1, y), J_(r, x + 1, y + 1));         /* f */
+    case 7: return AV(B_(r, x + 1, y), H_(r, x + 1, y + 1));         /* g */
+    case 9: return AV(H_(r, x, y + 1), J_(r, x + 1, y + 1));         /* i */
+    case 11: return AV(J_(r, x + 1, y + 1), H_(r, x + 1, y + 1));    /* k */
+    case 12: return AV(H_(r, x, y + 1), A_(r, x, y + 1));            /* L */
+    case 13: return AV(H_(r, x, y + 1), B_(r, x + 1, y + 1));        /* m */
+    case 14: return AV(J_(r, x + 1, y + 1), B_(r, x + 1, y + 1));    /* n */
+    default: return AV(H_(r, x + 1, y + 1), B_(r, x + 1, y + 1));    /* 15: o */
+    }
+#undef AV
+}
+
+static uint32_t bipred_sad(const uint8_t *src, int ss, const RefView *r0, int xo0, int yo0, uint32_t mv0, const RefView *r1,
+                           int xo1, int yo1, uint32_t mv1, int px, int py, int w, int h)
+{
+    const int16_t x0 = (int16_t)(mv0 & 0xffff), y0 = (int16_t)(mv0 >> 16), x1 = (int16_t)(mv1 & 0xffff), y1 = (int16_t)(mv1 >> 16);
+    const int f0 = ((uint8_t)x0 & 3) + (((uint8_t)y0 & 3) << 2), f1 = ((uint8_t)x1 & 3) + (((uint8_t)y1 & 3) << 2);
+    const int ix0 = (x0 >> 2) - xo0 + px, iy0 = (y0 >> 2) - yo0 + py, ix1 = (x1 >> 2) - xo1 + px, iy1 = (y1 >> 2) - yo1 + py;
+    uint32_t sad = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const int p0 = bipred_sample(r0, f0, ix0 + x, iy0 + y), p1 = bipred_sample(r1, f1, ix1 + x, iy1 + y);
+            const int avg = (p0 + p1 + 1) >> 1; /* NxMSadAveragingKernel / CombinedAveragingSAD, all rows (SSD_SEARCH mode) */
+            const int sv = src[(py + y) * ss + px + x];
+            sad += (uint32_t)(sv > avg ? sv - avg : avg - sv);
+        }
+    return sad;
+}
+
+/* raster PU index (me_results order) -> ME-buffer index (:6980-7015), square PUs only */
+static int me_index(int pu)
+{
+    if (pu > 20) return kTab8[pu - 21] + 21;
+    if (pu > 4) return kTab16[pu - 5] + 5;
+    return pu;
+}
+
+/* n_lists = 1 (P) or 2 (B).  sad/mv arrays are ME-buffer ordered [85]; out = 85 svthip_me_cu_result in raster PU order.
+ * bipred_8x8 = (cu8x8_mode == CU_8x8_MODE_0): 8x8 PUs get a bi-pred candidate too (:7028). */
+void orc_bipred_pack_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref0_00, uint32_t ref0_stride, int16_t xo0,
+                          int16_t yo0, const uint8_t *ref1_00, uint32_t ref1_stride, int16_t xo1, int16_t yo1,
+                          const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1, int n_lists,
+                          int bipred_8x8, svthip_me_cu_result *out)
+{
+    RefView r0 = {ref0_00, (int)ref0_stride}, r1 = {ref1_00, (int)ref1_stride};
+    for (int pu = 0; pu < 85; pu++) {
+        const int n = me_index(pu);
+        const int w = pu == 0 ? 64 : pu < 5 ? 32 : pu < 21 ? 16 : 8;
+        int px, py;
+        if (pu == 0) { px = py = 0; }
+        else if (pu < 5) { px = ((pu - 1) & 1) << 5; py = ((pu - 1) >> 1) << 5; }
+        else if (pu < 21) { px = ((pu - 5) & 3) << 4; py = ((pu - 5) >> 2) << 4; }
+        else { px = ((pu - 21) & 7) << 3; py = ((pu - 21) >> 3) << 3; }
+        svthip_me_cu_result *o = &out[pu];
+        int total = n_lists;
+        uint32_t bi = 0;
+        if (n_lists == 2 && (bipred_8x8 || pu < 21)) {
+            bi = bipred_sad(src, (int)src_stride, &r0, xo0, yo0, mv0[n], &r1, xo1, yo1, mv1[n], px, py, w, w);
+            total = 3;
+        }
+        o->xMvL0 = (int16_t)(mv0[n] & 0xffff);
+        o->yMvL0 = (int16_t)(mv0[n] >> 16);
+        o->xMvL1 = n_lists == 2 ? (int16_t)(mv1[n] & 0xffff) : 0; /* P pictures: list-1 fields are don't-care in the reference */
+        o->yMvL1 = n_lists == 2 ? (int16_t)(mv1[n] >> 16) : 0;
+        o->totalMeCandidateIndex = (uint8_t)total;
+        for (int k = 0; k < 3; k++) { o->distortion[k] = 0; o->direction[k] = 0; }
+        const uint32_t a = sad0[n], b = n_lists == 2 ? sad1[n] : 0, c = bi;
+        if (total == 3) {
+            /* Sort3Elements (:5434-5463): '<=' everywhere, ties favour L0, then L1 */
+            int order[3];
+            if (a <= b && a <= c) { order[0] = 0; if (b <= c) { order[1] = 1; order[2] = 2; } else { order[1] = 2; order[2] = 1; } }
+            else if (b <= a && b <= c) { order[0] = 1; if (a <= c) { order[1] = 0; order[2] = 2; } else { order[1] = 2; order[2] = 0; } }
+            else if (a <= b) { order[0] = 2; order[1] = 0; order[2] = 1; }
+            else { order[0] = 2; order[1] = 1; order[2] = 0; }
+            const uint32_t v[3] = {a, b, c};
+            for (int k = 0; k < 3; k++) { o->distortion[k] = v[order[k]]; o->direction[k] = (uint8_t)order[k]; }
+        } else if (total == 2) {
+            if (a <= b) { o->distortion[0] = a; o->direction[0] = 0; o->distortion[1] = b; o->direction[1] = 1; }
+            else { o->distortion[0] = b; o->direction[0] = 1; o->distortion[1] = a; o->direction[1] = 0; }
+        } else {
+            o->distortion[0] = a;
+            o->direction[0] = 0;
+        }
+    }
+}
+
+void orc_bipred_pack_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref0_plane, uint32_t ref0_stride,
+                           const int32_t *desc0, const uint8_t *ref1_plane, uint32_t ref1_stride, const int32_t *desc1,
+                           uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
+                           int n_lists, int bipred_8x8, svthip_me_cu_result *out)
+{
+    for (uint32_t i = 0; i < n_sb; i++) {
+        const int32_t *d0 = desc0 + 6 * i, *d1 = n_lists == 2 ? desc1 + 6 * i : d0;
+        orc_bipred_pack_85pu(src_plane + d0[0], src_stride, ref0_plane + d0[1], ref0_stride, (int16_t)d0[2], (int16_t)d0[3],
+                             (n_lists == 2 ? ref1_plane : ref0_plane) + d1[1], n_lists == 2 ? ref1_stride : ref0_stride,
+                             (int16_t)d1[2], (int16_t)d1[3], sad0 + 85 * i, mv0 + 85 * i, n_lists == 2 ? sad1 + 85 * i : sad0 + 85 * i,
+                             n_lists == 2 ? mv1 + 85 * i : mv0 + 85 * i, n_lists, bipred_8x8, out + 85 * i);
+    }
+}

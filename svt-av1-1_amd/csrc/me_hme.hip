@@ -303,7 +303,7 @@ struct HmeShared {
 __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_picture cur,
                                                          svthip_pa_picture ref, svthip_me_params P, uint32_t list_index,
                                                          const svthip_sb_origin* __restrict__ sbs,
-                                                         const uint32_t* __restrict__ l0_best_mv64,
+                                                         const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
                                                          svthip_fullpel_desc* __restrict__ out_desc,
                                                          int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state)
 {
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
     const uint8_t* src = cur_full + (size_t)oy * cur.full_stride + ox;
 
     const bool center_path = (P.temporal_layer_index > 0) || (list_index == 0);  // :6300
-    const uint32_t mv64 = (list_index == 1 && l0_best_mv64) ? l0_best_mv64[sbi] : 0u;
+    const uint32_t mv64 = (list_index == 1 && l0_best_mv64) ? l0_best_mv64[(size_t)sbi * l0_mv_stride] : 0u;
     const int dx = s16(0 - (s16((int)(mv64 & 0xffffu)) >> 2));
     const int dy = s16(0 - (s16((int)(mv64 >> 16)) >> 2));
     const int tw = P.hme_level0_total_search_area_width, th = P.hme_level0_total_search_area_height;

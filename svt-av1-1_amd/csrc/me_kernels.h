@@ -24,13 +24,22 @@ __global__ void fullpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t
 
 __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_picture cur, svthip_pa_picture ref,
                                   svthip_me_params P, uint32_t list_index, const svthip_sb_origin* __restrict__ sbs,
-                                  const uint32_t* __restrict__ l0_best_mv64, svthip_fullpel_desc* __restrict__ out_desc,
+                                  const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
+                                  svthip_fullpel_desc* __restrict__ out_desc,
                                   int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                 const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
                                 int disable_8x8, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv);
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
+__global__ void bipred_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                   const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride, const int32_t* __restrict__ desc0,
+                                   const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride, const int32_t* __restrict__ desc1,
+                                   const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,
+                                   const uint32_t* __restrict__ sad1, const uint32_t* __restrict__ mv1, int n_lists, int bipred_8x8,
+                                   int win_bytes, svthip_me_cu_result* __restrict__ out);
+size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh);
+size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 

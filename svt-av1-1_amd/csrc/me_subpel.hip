@@ -318,6 +318,211 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Bi-prediction SAD + result packing (Codec/EbMotionEstimation.c:6973-7146).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+// prediction sample of one list at fractional position frac = (x_mv & 3) + ((y_mv & 3) << 2); (x,y) = integer position
+// in search-region coordinates.  F = A(x,y), Bq = b(x+1,y), Hq = h(x,y+1), Jq = j(x+1,y+1) are the samples
+// BiPredictionCompensation's buffer indices select (:5155-5158); quarter positions average two of them
+// (QuarterPelCompensation :4844-4910).
+template <int TWd>
+__device__ __forceinline__ int bipred_sample(const Win& win, const Tiles<TWd>& t, int frac, int x, int y, int bx, int by)
+{
+    const int tx = x - (bx - 2), ty = y - (by - 2);
+#define AV(a, b) (((a) + (b) + 1) >> 1)
+    switch (frac) {
+    case 0: return win.at(x, y);
+    case 2: return t.b(tx + 1, ty);
+    case 8: return t.h(tx, ty + 1);
+    case 10: return t.j(tx + 1, ty + 1);
+    case 1: return AV(win.at(x, y), t.b(tx + 1, ty));
+    case 3: return AV(t.b(tx + 1, ty), win.at(x + 1, y));
+    case 4: return AV(win.at(x, y), t.h(tx, ty + 1));
+    case 5: return AV(t.b(tx + 1, ty), t.h(tx, ty + 1));
+    case 6: return AV(t.b(tx + 1, ty), t.j(tx + 1, ty + 1));
+    case 7: return AV(t.b(tx + 1, ty), t.h(tx + 1, ty + 1));
+    case 9: return AV(t.h(tx, ty + 1), t.j(tx + 1, ty + 1));
+    case 11: return AV(t.j(tx + 1, ty + 1), t.h(tx + 1, ty + 1));
+    case 12: return AV(t.h(tx, ty + 1), win.at(x, y + 1));
+    case 13: return AV(t.h(tx, ty + 1), t.b(tx + 1, ty + 1));
+    case 14: return AV(t.j(tx + 1, ty + 1), t.b(tx + 1, ty + 1));
+    default: return AV(t.h(tx + 1, ty + 1), t.b(tx + 1, ty + 1));
+    }
+#undef AV
+}
+
+// bi-pred SAD of one PU by one wave: list-0 prediction goes through `pred0` (PW*PW bytes of LDS) so the tile
+// memory can be reused for list 1
+template <int PW>
+__device__ uint32_t bipred_pu(const uint8_t* src, const Win& win0, const Win& win1, Tiles<PW>& t, uint8_t* pred0, int px, int py,
+                              uint32_t mv0, int xo0, int yo0, uint32_t mv1, int xo1, int yo1, int lane)
+{
+    const int x0 = (int)(int16_t)(mv0 & 0xffffu), y0 = (int)(int16_t)(mv0 >> 16);
+    const int x1 = (int)(int16_t)(mv1 & 0xffffu), y1 = (int)(int16_t)(mv1 >> 16);
+    const int f0 = (x0 & 3) + ((y0 & 3) << 2), f1 = (x1 & 3) + ((y1 & 3) << 2);
+    const int bx0 = (x0 >> 2) - xo0 + px, by0 = (y0 >> 2) - yo0 + py;
+    const int bx1 = (x1 >> 2) - xo1 + px, by1 = (y1 >> 2) - yo1 + py;
+    if (f0) fill_tiles<PW>(win0, t, bx0, by0, lane);
+    for (int i = lane; i < PW * PW; i += 64) {
+        const int y = i / PW, x = i - y * PW;
+        pred0[i] = (uint8_t)bipred_sample<PW>(win0, t, f0, bx0 + x, by0 + y, bx0, by0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (f1) fill_tiles<PW>(win1, t, bx1, by1, lane);
+    uint32_t sad = 0;
+    for (int i = lane; i < PW * PW; i += 64) {
+        const int y = i / PW, x = i - y * PW;
+        const int p1 = bipred_sample<PW>(win1, t, f1, bx1 + x, by1 + y, bx1, by1);
+        const int avg = ((int)pred0[i] + p1 + 1) >> 1;
+        sad += (uint32_t)abs((int)src[(py + y) * 64 + px + x] - avg);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return wsum(sad);
+}
+
+__device__ void stage_window(uint8_t* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid)
+{
+    const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
+    const uint32_t shf = (uint32_t)(a0 & 3u);
+    const uint32_t* base4 = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+    const int ndw = pitch >> 2, rstride4 = ref_stride >> 2;
+    const int total = wrows * ndw;
+    const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;
+    for (int i = tid; i < total; i += 256) {
+        const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
+        const uint32_t* p = base4 + (size_t)r * rstride4 + c;
+        reinterpret_cast<uint32_t*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                                          const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride,
+                                                          const int32_t* __restrict__ desc0,
+                                                          const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride,
+                                                          const int32_t* __restrict__ desc1, const uint32_t* __restrict__ sad0,
+                                                          const uint32_t* __restrict__ mv0, const uint32_t* __restrict__ sad1,
+                                                          const uint32_t* __restrict__ mv1, int n_lists, int bipred_8x8,
+                                                          int win_bytes, svthip_me_cu_result* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t bisad[85];  // indexed by ME-buffer PU index
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t sb = blockIdx.x;
+    const uint32_t* s0 = sad0 + 85 * sb;
+    const uint32_t* m0 = mv0 + 85 * sb;
+    const uint32_t* s1 = n_lists == 2 ? sad1 + 85 * sb : s0;
+    const uint32_t* m1 = n_lists == 2 ? mv1 + 85 * sb : m0;
+
+    if (n_lists == 2) {
+        const int32_t* d0 = desc0 + 6 * sb;
+        const int32_t* d1 = desc1 + 6 * sb;
+        // LDS: [src 4096][pred0 64|32|16|8][tiles 64|32|16|8][window 0][window 1]
+        uint8_t* src_lds = smem;
+        uint8_t* pred_base = smem + 4096;
+        uint8_t* tile_base = pred_base + 4096 + 1024 + 256 + 64;
+        constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
+        uint8_t* w0buf = tile_base + ((t64 + t32 + t16 + t8 + 15) & ~15);
+        uint8_t* w1buf = w0buf + win_bytes;
+        const int pitch0 = (d0[4] + 63 + 2 * kMargin + 3) & ~3, pitch1 = (d1[4] + 63 + 2 * kMargin + 3) & ~3;
+        for (int i = tid; i < 64 * 16; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            reinterpret_cast<uint32_t*>(src_lds)[i] =
+                *reinterpret_cast<const uint32_t*>(src_plane + d0[0] + (size_t)r * src_stride + 4 * c);
+        }
+        stage_window(w0buf, pitch0, d0[5] + 63 + 2 * kMargin, ref0_plane, d0[1], ref0_stride, tid);
+        stage_window(w1buf, pitch1, d1[5] + 63 + 2 * kMargin, ref1_plane, d1[1], ref1_stride, tid);
+        __syncthreads();
+        Win win0{w0buf, pitch0}, win1{w1buf, pitch1};
+        const int xo0 = d0[2], yo0 = d0[3], xo1 = d1[2], yo1 = d1[3];
+        if (wave == 0) {
+            Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
+            const uint32_t v = bipred_pu<64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
+            if (lane == 0) bisad[0] = v;
+        } else if (wave == 1) {
+            uint8_t* b = tile_base + t64;
+            Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
+            for (int p = 0; p < 4; p++) {
+                const uint32_t v = bipred_pu<32>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p], xo0,
+                                                 yo0, m1[1 + p], xo1, yo1, lane);
+                if (lane == 0) bisad[1 + p] = v;
+            }
+        } else if (wave == 2) {
+            uint8_t* b = tile_base + t64 + t32;
+            Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
+            for (int p = 0; p < 16; p++) {
+                const int n = 5 + kTab16[p];
+                const uint32_t v = bipred_pu<16>(src_lds, win0, win1, t, pred_base + 4096 + 1024, (p & 3) << 4, (p >> 2) << 4, m0[n],
+                                                 xo0, yo0, m1[n], xo1, yo1, lane);
+                if (lane == 0) bisad[n] = v;
+            }
+        } else if (bipred_8x8) {
+            uint8_t* b = tile_base + t64 + t32 + t16;
+            Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
+            for (int p = 0; p < 64; p++) {
+                const int n = 21 + kTab8[p];
+                const uint32_t v = bipred_pu<8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + 256, (p & 7) << 3, (p >> 3) << 3,
+                                                m0[n], xo0, yo0, m1[n], xo1, yo1, lane);
+                if (lane == 0) bisad[n] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (tid < 85) {
+        // me_results[sb][pu] in raster PU order; n = ME-buffer index (:6980-7015)
+        const int pu = tid;
+        const int n = pu > 20 ? kTab8[pu - 21] + 21 : (pu > 4 ? kTab16[pu - 5] + 5 : pu);
+        svthip_me_cu_result o;
+        o.xMvL0 = (int16_t)(m0[n] & 0xffffu);
+        o.yMvL0 = (int16_t)(m0[n] >> 16);
+        o.xMvL1 = n_lists == 2 ? (int16_t)(m1[n] & 0xffffu) : 0;
+        o.yMvL1 = n_lists == 2 ? (int16_t)(m1[n] >> 16) : 0;
+        for (int k = 0; k < 3; k++) { o.distortion[k] = 0; o.direction[k] = 0; }
+        const uint32_t a = s0[n], b = n_lists == 2 ? s1[n] : 0u;
+        int total = n_lists;
+        if (n_lists == 2 && (bipred_8x8 || pu < 21)) total = 3;
+        if (total == 3) {
+            const uint32_t c = bisad[n];
+            int o0, o1, o2;  // Sort3Elements (:5434-5463)
+            if (a <= b && a <= c) { o0 = 0; if (b <= c) { o1 = 1; o2 = 2; } else { o1 = 2; o2 = 1; } }
+            else if (b <= a && b <= c) { o0 = 1; if (a <= c) { o1 = 0; o2 = 2; } else { o1 = 2; o2 = 0; } }
+            else if (a <= b) { o0 = 2; o1 = 0; o2 = 1; }
+            else { o0 = 2; o1 = 1; o2 = 0; }
+            const uint32_t v[3] = {a, b, c};
+            o.distortion[0] = v[o0]; o.direction[0] = (uint8_t)o0;
+            o.distortion[1] = v[o1]; o.direction[1] = (uint8_t)o1;
+            o.distortion[2] = v[o2]; o.direction[2] = (uint8_t)o2;
+        } else if (total == 2) {
+            if (a <= b) { o.distortion[0] = a; o.direction[0] = 0; o.distortion[1] = b; o.direction[1] = 1; }
+            else { o.distortion[0] = b; o.direction[0] = 1; o.distortion[1] = a; o.direction[1] = 0; }
+        } else {
+            o.distortion[0] = a;
+            o.direction[0] = 0;
+        }
+        o.totalMeCandidateIndex = (uint8_t)total;
+        out[85 * sb + pu] = o;
+    }
+}
+
+size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh)
+{
+    const size_t pitch = (max_sw + 63 + 2 * kMargin + 3) & ~(size_t)3;
+    return (pitch * (max_sh + 63 + 2 * kMargin) + 15) & ~(size_t)15;
+}
+
+size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh)
+{
+    const size_t tiles = (Tiles<64>::bytes + Tiles<32>::bytes + Tiles<16>::bytes + Tiles<8>::bytes + 15) & ~(size_t)15;
+    return 4096 + (4096 + 1024 + 256 + 64) + tiles + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
+}
+
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
     const size_t tiles = (Tiles<64>::bytes + Tiles<32>::bytes + Tiles<16>::bytes + Tiles<8>::bytes + 15) & ~(size_t)15;

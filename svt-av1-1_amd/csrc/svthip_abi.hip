@@ -160,10 +160,45 @@ int32_t svthip_me_subpel_refine_dev(svthip_ctx* ctx, const uint8_t* d_src_plane,
     return SVTHIP_OK;
 }
 
+int32_t svthip_me_bipred_pack_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref0_plane,
+                                  uint32_t ref0_stride, const svthip_fullpel_desc* d_desc0, const uint8_t* d_ref1_plane,
+                                  uint32_t ref1_stride, const svthip_fullpel_desc* d_desc1, uint32_t n_sb,
+                                  uint32_t max_search_area_width, uint32_t max_search_area_height, const uint32_t* d_sad0,
+                                  const uint32_t* d_mv0, const uint32_t* d_sad1, const uint32_t* d_mv1, uint32_t n_lists,
+                                  int32_t bipred_8x8, svthip_me_cu_result* d_out, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (n_lists < 1 || n_lists > 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_lists must be 1 or 2%s", "");
+    if (!d_sad0 || !d_mv0 || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    size_t lds = 0;
+    int win_bytes = 0;
+    if (n_lists == 2) {
+        if (!d_src_plane || !d_ref0_plane || !d_ref1_plane || !d_desc0 || !d_desc1 || !d_sad1 || !d_mv1)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+        if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127%s", "");
+        if ((src_stride & 3u) || (ref0_stride & 3u) || (ref1_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
+        lds = svthip::bipred_lds_bytes(max_search_area_width, max_search_area_height);
+        win_bytes = (int)svthip::subpel_window_bytes(max_search_area_width, max_search_area_height);
+        if (lds > 160 * 1024) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS windows%s", "");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_pack_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::bipred_pack_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
+                       reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
+                       d_sad0, d_mv0, d_sad1, d_mv1, (int)n_lists, (int)bipred_8x8, win_bytes, d_out);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                         const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
                                         const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,
-                                        svthip_fullpel_desc* d_desc, int16_t* d_center, int16_t* d_hme_state, void* stream)
+                                        uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc, int16_t* d_center,
+                                        int16_t* d_hme_state, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (n_sb == 0) return SVTHIP_OK;
@@ -184,9 +219,54 @@ int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, 
     if (max_off > 0x7fffffffLL) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture pool offsets must fit 31 bits%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb), dim3(256), 0, s, d_pool, *cur, *ref, P, list_index, d_sb,
-                       d_l0_best_mv64, d_desc, d_center, d_hme_state);
+                       d_l0_best_mv64, l0_mv_stride ? l0_mv_stride : 1u, d_desc, d_center, d_hme_state);
     HIP_TRY(hipGetLastError());
     return SVTHIP_OK;
+}
+
+int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                           const svthip_pa_picture* ref0, const svthip_pa_picture* ref1,
+                                           const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                           const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
+                                           uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (!d_pool || !cur || !ref0 || !params || !d_sb || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n_lists = ref1 ? 2u : 1u;
+    // scratch: slot 5 holds  desc[2][n] | sad[2][n][85] | mv[2][n][85] | hme_state[n][25]
+    const size_t desc_b = sizeof(svthip_fullpel_desc) * n_sb, arr_b = sizeof(uint32_t) * 85 * (size_t)n_sb;
+    const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * (size_t)n_sb) + 15) & ~(size_t)15;
+    int32_t rc;
+    if ((rc = ensure_scratch(ctx, 5, 2 * desc_b + 4 * arr_b + state_b + 64))) return rc;
+    uint8_t* base = static_cast<uint8_t*>(ctx->scratch[5]);
+    svthip_fullpel_desc* desc[2] = {reinterpret_cast<svthip_fullpel_desc*>(base), reinterpret_cast<svthip_fullpel_desc*>(base + desc_b)};
+    uint32_t* sad[2] = {reinterpret_cast<uint32_t*>(base + 2 * desc_b), reinterpret_cast<uint32_t*>(base + 2 * desc_b + arr_b)};
+    uint32_t* mv[2] = {reinterpret_cast<uint32_t*>(base + 2 * desc_b + 2 * arr_b), reinterpret_cast<uint32_t*>(base + 2 * desc_b + 3 * arr_b)};
+    int16_t* state = reinterpret_cast<int16_t*>(base + 2 * desc_b + 4 * arr_b);
+    if (d_list_sad && d_list_mv) {  // caller wants the per-list arrays: write them in place
+        sad[0] = d_list_sad; sad[1] = d_list_sad + 85 * (size_t)n_sb;
+        mv[0] = d_list_mv; mv[1] = d_list_mv + 85 * (size_t)n_sb;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint32_t sw = params->search_area_width < 127 ? params->search_area_width : 127;
+    const uint32_t sh = params->search_area_height < 127 ? params->search_area_height : 127;
+    const svthip_pa_picture* refs[2] = {ref0, ref1};
+    for (uint32_t l = 0; l < n_lists; l++) {
+        if ((rc = svthip_me_hme_search_center_dev(ctx, d_pool, cur, refs[l], params, l, d_sb, n_sb, l ? mv[0] : nullptr, 85, desc[l],
+                                                  nullptr, state, s)))
+            return rc;
+        if ((rc = launch_fullpel(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], n_sb, sw, sh, sad[l], mv[l], s)))
+            return rc;
+        if (use_subpel_flag &&
+            (rc = svthip_me_subpel_refine_dev(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], n_sb, sw, sh,
+                                              cu8x8_mode == 1, sad[l], mv[l], s)))
+            return rc;
+    }
+    return svthip_me_bipred_pack_dev(ctx, d_pool, cur->full_stride, d_pool, ref0->full_stride, desc[0], n_lists == 2 ? d_pool : nullptr,
+                                     n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, n_sb, sw, sh, sad[0], mv[0],
+                                     n_lists == 2 ? sad[1] : nullptr, n_lists == 2 ? mv[1] : nullptr, n_lists, cu8x8_mode == 0, d_out, s);
 }
 
 int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size_t src_plane_bytes, uint32_t src_stride,

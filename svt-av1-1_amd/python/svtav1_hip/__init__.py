@@ -65,11 +65,19 @@ def lib() -> C.CDLL:
                                                     C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
     L.svthip_me_hme_search_center_dev.restype = C.c_int32
     L.svthip_me_hme_search_center_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
-                                                  C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                  C.c_void_p]
+                                                  C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]
+    L.svthip_motion_estimate_picture_dev.restype = C.c_int32
+    L.svthip_motion_estimate_picture_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p]
     L.svthip_me_subpel_refine_dev.restype = C.c_int32
     L.svthip_me_subpel_refine_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svthip_me_bipred_pack_dev.restype = C.c_int32
+    L.svthip_me_bipred_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -138,10 +146,22 @@ class Context:
 
 
 def _hme_search_center_dev(self, d_pool, cur, ref, params, list_index, d_sb, n_sb, d_l0_mv64, d_desc, d_center=None,
-                           d_state=None, stream=None):
+                           d_state=None, stream=None, l0_mv_stride=1):
     """cur/ref: PaPictureDesc, params: MeParams (host structs); the rest are device addresses."""
     _check(lib().svthip_me_hme_search_center_dev(self._h, d_pool, C.byref(cur), C.byref(ref), C.byref(params), list_index,
-                                                 d_sb, n_sb, d_l0_mv64, d_desc, d_center, d_state, stream))
+                                                 d_sb, n_sb, d_l0_mv64, l0_mv_stride, d_desc, d_center, d_state, stream))
+
+
+def _motion_estimate_picture_dev(self, d_pool, cur, ref0, ref1, params, d_sb, n_sb, d_out, use_subpel=True, cu8x8_mode=0,
+                                 d_list_sad=None, d_list_mv=None, stream=None):
+    """Whole-picture ME (MotionEstimateLcu over all SBs): ref1=None for P pictures."""
+    _check(lib().svthip_motion_estimate_picture_dev(self._h, d_pool, C.byref(cur), C.byref(ref0),
+                                                    C.byref(ref1) if ref1 is not None else None, C.byref(params),
+                                                    int(use_subpel), int(cu8x8_mode), d_sb, n_sb, d_out, d_list_sad, d_list_mv,
+                                                    stream))
+
+
+Context.motion_estimate_picture_dev = _motion_estimate_picture_dev
 
 
 Context.hme_search_center_dev = _hme_search_center_dev
@@ -154,6 +174,16 @@ def _subpel_refine_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb,
 
 
 Context.subpel_refine_dev = _subpel_refine_dev
+
+
+def _bipred_pack_dev(self, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_ref1, ref1_stride, d_desc1, n_sb, max_sw, max_sh,
+                     d_sad0, d_mv0, d_sad1, d_mv1, n_lists, d_out, bipred_8x8=True, stream=None):
+    _check(lib().svthip_me_bipred_pack_dev(self._h, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_ref1, ref1_stride, d_desc1,
+                                           n_sb, max_sw, max_sh, d_sad0, d_mv0, d_sad1, d_mv1, n_lists, int(bipred_8x8), d_out,
+                                           stream))
+
+
+Context.bipred_pack_dev = _bipred_pack_dev
 
 
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
@@ -195,6 +225,16 @@ class MeParams(C.Structure):
                 ("enable_hme_flag", C.c_uint8), ("enable_hme_level0_flag", C.c_uint8), ("enable_hme_level1_flag", C.c_uint8),
                 ("enable_hme_level2_flag", C.c_uint8), ("temporal_layer_index", C.c_uint8),
                 ("is_used_as_reference_flag", C.c_uint8), ("ref_poc_equal", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class MeCuResult(C.Structure):
+    _fields_ = [("xMvL0", C.c_int16), ("yMvL0", C.c_int16), ("xMvL1", C.c_int16), ("yMvL1", C.c_int16),
+                ("distortion", C.c_uint32 * 3), ("direction", C.c_uint8 * 3), ("totalMeCandidateIndex", C.c_uint8)]
+
+
+ME_CU_RESULT_DTYPE = np.dtype([("xMvL0", "<i2"), ("yMvL0", "<i2"), ("xMvL1", "<i2"), ("yMvL1", "<i2"), ("distortion", "<u4", 3),
+                               ("direction", "u1", 3), ("totalMeCandidateIndex", "u1")])
+assert ME_CU_RESULT_DTYPE.itemsize == C.sizeof(MeCuResult) == 24
 
 
 class SbOrigin(C.Structure):

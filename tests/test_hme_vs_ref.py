@@ -75,6 +75,30 @@ def test_chain_matches_reference_motion_estimate_lcu(oracle, refme, case):
         assert np.array_equal(m, ref["mv"][:, l]), f"list {l}: MVs differ"
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[2] != "flat"])
+def test_bipred_and_packing_match_reference(oracle, refme, case):
+    """me_results of the reference (bi-prediction SAD at integer MVs + Sort3Elements ordering) vs the oracle's
+    orc_bipred_pack_* fed with the oracle chain's per-list results."""
+    w, h, kind, hier, tl, two, is_ref, poc_eq = case
+    pics = _pics(w, h, kind)
+    P = svtav1_hip.default_me_params(w, h, hier, tl, is_ref, poc_eq)
+    ref = refme.run(pics[0], pics[1], pics[2], P, two_lists=two, hierarchical_levels=hier)
+    mine = oracle_chain(oracle, pics, P, two)
+    pool, descs = svtav1_hip.build_picture_pool(pics)
+    fs = descs[0].full_stride
+    if two:
+        res = oracle.bipred_pack_batch(pool, fs, pool, fs, mine[0][0], mine[0][1], mine[0][2], pool, fs, mine[1][0], mine[1][1], mine[1][2])
+    else:
+        res = oracle.bipred_pack_batch(pool, fs, pool, fs, mine[0][0], mine[0][1], mine[0][2])
+    r = ref["res"]  # [n,85,9] = xMvL0,yMvL0,xMvL1,yMvL1, dist0,dir0, dist1,dir1, total
+    assert np.array_equal(res["totalMeCandidateIndex"], r[:, :, 8])
+    assert np.array_equal(res["xMvL0"], r[:, :, 0]) and np.array_equal(res["yMvL0"], r[:, :, 1])
+    assert np.array_equal(res["distortion"][:, :, 0], r[:, :, 4].astype(np.uint32)) and np.array_equal(res["direction"][:, :, 0], r[:, :, 5])
+    if two:
+        assert np.array_equal(res["xMvL1"], r[:, :, 2]) and np.array_equal(res["yMvL1"], r[:, :, 3])
+        assert np.array_equal(res["distortion"][:, :, 1], r[:, :, 6].astype(np.uint32)) and np.array_equal(res["direction"][:, :, 1], r[:, :, 7])
+
+
 def test_hme_disabled_levels(oracle, refme):
     pics = _pics(448, 320, "pan")
     for flags in [(1, 0, 0), (1, 1, 0), (0, 1, 1), (0, 0, 0)]:

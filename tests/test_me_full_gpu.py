@@ -1,0 +1,69 @@
+"""GPU parity of the whole-picture ME entry (svthip_motion_estimate_picture_dev): HME -> full-pel -> sub-pel per list,
+bi-prediction, packed me_results, vs the oracle chain.  Bit-exact."""
+import numpy as np
+import pytest
+
+import svtav1_hip
+from svtav1_hip import synth
+from me_chain_util import compare_results, device_me_picture, oracle_me_picture
+
+pytestmark = pytest.mark.gpu
+
+
+def _pics(w, h, kind):
+    if kind == "synth":
+        f = [synth.synth_luma(w, h, t) for t in (3, 0, 7)]
+    elif kind == "pan":
+        big = synth.synth_luma(w + 128, h + 96, 0)
+        f = [big[40:40 + h, 50:50 + w], big[30:30 + h, 14:14 + w], big[70:70 + h, 100:100 + w]]
+    elif kind == "smooth":
+        yy, xx = np.mgrid[0:h + 64, 0:w + 64]
+        big = np.clip(128 + 60 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 40 * np.sin((xx + 2 * yy) / 23.0), 0, 255).astype(np.uint8)
+        f = [big[20:20 + h, 20:20 + w], big[17:17 + h, 25:25 + w], big[26:26 + h, 12:12 + w]]
+    else:
+        rng = np.random.default_rng(5)
+        f = [rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(3)]
+    return [synth.PaPicture(np.ascontiguousarray(x)) for x in f]
+
+
+CASES = [
+    # w, h, kind, hier, tl, two_lists, use_subpel, cu8x8_mode
+    (320, 192, "pan", 3, 0, False, True, 0),
+    (320, 192, "pan", 3, 1, True, True, 0),
+    (320, 192, "smooth", 3, 1, True, True, 0),
+    (320, 192, "smooth", 4, 2, True, True, 1),
+    (320, 192, "random", 3, 2, True, True, 0),
+    (328, 200, "pan", 3, 1, True, True, 0),       # partial right column / bottom row
+    (320, 192, "pan", 3, 1, True, False, 0),      # sub-pel off (the configuration the reference binary can run)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_motion_estimate_picture_matches_oracle(hip_ctx, oracle, case):
+    pytest.importorskip("torch")
+    w, h, kind, hier, tl, two, subpel, cu8 = case
+    pics = _pics(w, h, kind)
+    P = svtav1_hip.default_me_params(w, h, hier, tl)
+    res_o, per = oracle_me_picture(oracle, pics, P, two, subpel, cu8)
+    res_d, ls, lm = device_me_picture(hip_ctx, pics, P, two, subpel, cu8)
+    for l in per:
+        assert np.array_equal(ls[l], per[l][1]), f"list {l} SADs"
+        assert np.array_equal(lm[l], per[l][2]), f"list {l} MVs"
+    compare_results(res_d, res_o)
+
+
+def test_motion_estimate_picture_1080p_b_picture(hip_ctx, oracle):
+    """Full-size B picture through the whole chain; a sample of SBs against the oracle chain."""
+    pytest.importorskip("torch")
+    pics = _pics(1920, 1080, "synth")
+    P = svtav1_hip.default_me_params(1920, 1080, 3, 1)
+    res_d, ls, lm = device_me_picture(hip_ctx, pics, P, True, True, 0)
+    assert (res_d["totalMeCandidateIndex"] == 3).all()
+    # sorted candidates
+    d = res_d["distortion"]
+    assert (d[:, :, 0] <= d[:, :, 1]).all() and (d[:, :, 1] <= d[:, :, 2]).all()
+    sample = np.sort(np.random.default_rng(17).choice(510, 16, replace=False))
+    res_o, per = oracle_me_picture(oracle, pics, P, True, True, 0, sb_subset=sample)
+    for l in per:
+        assert np.array_equal(ls[l][sample], per[l][1]) and np.array_equal(lm[l][sample], per[l][2])
+    compare_results(res_d[sample], res_o)
