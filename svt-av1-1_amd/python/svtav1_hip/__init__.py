@@ -310,3 +310,14 @@ def sb_origins(width: int, height: int) -> np.ndarray:
         for sx in range(nx):
             out[sy * nx + sx] = (sx * 64, sy * 64)
     return out
+
+
+def shard_sb_rows(width: int, height: int, world: int, rank: int) -> np.ndarray:
+    """Contiguous SB-row partition of one picture across `world` ranks (1080p -> 17 rows -> 3/2/2/...):
+    returns the indices (into sb_origins(width, height)) of the SBs rank `rank` owns.  ME is open-loop, so shards need
+    no exchange: every rank holds the (read-only) planes and writes only its own rows of me_results."""
+    nx, ny = (width + 63) // 64, (height + 63) // 64
+    base, extra = divmod(ny, world)
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return np.arange(first * nx, (first + count) * nx, dtype=np.int64)

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REFERENCE's own code (oracle/_ref, built by oracle/build_ref.sh from
+/root/reference).  Run in the build container only; the fixtures are data (inputs + reference outputs) and are what
+the GPU box checks against, since /root/reference does not exist there.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "svt-av1-1_amd", "python"))
+
+import svtav1_hip  # noqa: E402
+from oracle.binding import Reference, ReferenceME  # noqa: E402
+from svtav1_hip import synth  # noqa: E402
+
+
+def fullpel_fixture():
+    """Full-pel 85-PU search through the reference's SSE4.1 8-position + SSE2 single-position kernels."""
+    ref = Reference()
+    rng = np.random.default_rng(20261004)
+    w, h = 192, 136
+    cur_img = synth.synth_luma(w, h, 1)
+    ref_img = synth.synth_luma(w, h, 0)
+    cur, rf = synth.PaPicture(cur_img), synth.PaPicture(ref_img)
+    cases = {}
+    for name, search in (("s64", (64, 64)), ("s23x9", (23, 9)), ("s127", (127, 127))):
+        centers = rng.integers(-40, 41, size=(9, 2))
+        desc = svtav1_hip.make_fullpel_desc(cur, rf, centers, *search)
+        sad, mv = ref.fullpel_search_batch(cur.full, rf.full, desc, asm_type=0)
+        cases[name + "_desc"] = desc
+        cases[name + "_sad"] = sad
+        cases[name + "_mv"] = mv
+    np.savez_compressed(os.path.join(HERE, "fullpel_85pu.npz"), cur=cur_img, ref=ref_img, **cases)
+
+
+def me_chain_fixture():
+    """MotionEstimateLcu (sub-pel off) on a panning B picture: per-list origins / SAD / MV and packed me_results."""
+    refme = ReferenceME()
+    w, h = 320, 192
+    big = synth.synth_luma(w + 128, h + 96, 0)
+    imgs = [np.ascontiguousarray(big[40:40 + h, 50:50 + w]), np.ascontiguousarray(big[30:30 + h, 14:14 + w]),
+            np.ascontiguousarray(big[70:70 + h, 100:100 + w])]
+    pics = [synth.PaPicture(x) for x in imgs]
+    P = svtav1_hip.default_me_params(w, h, 3, 1)
+    out = refme.run(pics[0], pics[1], pics[2], P, two_lists=True, hierarchical_levels=3)
+    np.savez_compressed(os.path.join(HERE, "me_lcu_b_picture.npz"), cur=imgs[0], ref0=imgs[1], ref1=imgs[2],
+                        hierarchical_levels=3, temporal_layer=1, sad=out["sad"], mv=out["mv"], origin=out["origin"],
+                        res=out["res"])
+
+
+def interp_fixture():
+    refme = ReferenceME()
+    img = np.random.default_rng(7).integers(0, 256, (160, 224), dtype=np.uint8)
+    plane = synth.pad_plane(img, synth.PAD_FULL)
+    off = (synth.PAD_FULL + 40) * plane.shape[1] + synth.PAD_FULL + 60
+    b, hh, j = refme.interp_region(plane, off, 24, 16, 16 + 64, 24 + 64)
+    np.savez_compressed(os.path.join(HERE, "interp_planes.npz"), img=img, off=off, sw=24, sh=16, b=b, h=hh, j=j)
+
+
+if __name__ == "__main__":
+    fullpel_fixture()
+    me_chain_fixture()
+    interp_fixture()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
