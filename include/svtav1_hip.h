@@ -213,6 +213,35 @@ int32_t svthip_motion_estimate_picture_dev(svthip_ctx *ctx, const uint8_t *d_poo
                                            const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
                                            uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batched quantisation + dequantisation + eob of transform units.
+ * Replaces aom_quantize_b / aom_quantize_b_32x32 / aom_quantize_b_64x64 (RTCD, Codec/aom_dsp_rtcd.h:310-331; C bodies
+ * aom_quantize_b*_c_II, Codec/EbFullLoop.c:109-143) and aom_highbd_quantize_b* (:301-336) as called by
+ * av1_quantize_b_facade_II / av1_highbd_quantize_b_facade (:596-664) with the flat quantisation matrix.
+ *
+ * d_coeff / d_qcoeff / d_dqcoeff : int32 pools; TU i occupies [coeff_offset, coeff_offset + n_coeffs) in all three
+ *                                  (coeff_offset multiple of 4; n_coeffs = 16, 64, 256 or 1024: transform sizes up to 32x32,
+ *                                  64-point transforms are quantised on their 32x32 top-left part like the reference).
+ * d_qparams  : int16 [n_rows][10] = zbin[2], round[2], quant[2], quant_shift[2], dequant[2] (index 0 DC, 1 AC): one row of
+ *              Quants/Dequants per (qindex, plane) as built by av1_build_quantizer
+ *              (Codec/EbModeDecisionConfigurationProcess.c:417-506); the host builds and uploads it once per picture.
+ * d_iscan    : int16 pool of INVERSE scan tables (SCAN_ORDER::iscan of av1_scan_orders[tx_size][tx_type],
+ *              Codec/EbFullLoop.c:826); iscan_offset (multiple of 4) selects the TU's table.
+ * d_eob[i]   : uint16, 1 + last scan position with a non-zero level (0 = empty block).
+ * Outputs are fully written (the reference memsets q/dq first, :60-61). */
+typedef struct svthip_quant_desc {
+    uint32_t coeff_offset;
+    uint32_t iscan_offset;
+    uint32_t qparam_index;
+    uint16_t n_coeffs;
+    uint8_t log_scale;  /* 0: up to 16x16-class, 1: 32x32-class, 2: 64x64-class (av1_get_tx_scale) */
+    uint8_t highbd;     /* 0: 8-bit path (int16 clamp, quantize_b_helper_c_II), 1: high bit-depth path */
+} svthip_quant_desc;
+
+int32_t svthip_quantize_b_batch_dev(svthip_ctx *ctx, const int32_t *d_coeff, const svthip_quant_desc *d_desc, uint32_t n_tu,
+                                    const int16_t *d_qparams, const int16_t *d_iscan, int32_t *d_qcoeff, int32_t *d_dqcoeff,
+                                    uint16_t *d_eob, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

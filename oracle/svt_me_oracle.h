@@ -90,6 +90,12 @@ void orc_bipred_pack_batch(const uint8_t *src_plane, uint32_t src_stride, const 
                            uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
                            int n_lists, int bipred_8x8, svthip_me_cu_result *out);
 
+/* ---- transform / quantisation (oracle/svt_tq_oracle.c) ---- */
+/* aom_quantize_b{,_32x32,_64x64}_c_II (highbd = 0) / aom_highbd_quantize_b*_c (highbd = 1), flat qmatrix.
+ * qp = {zbin[2], round[2], quant[2], quant_shift[2], dequant[2]} */
+void orc_quantize_b(const int32_t *coeff, int32_t n_coeffs, const int16_t *qp, const int16_t *scan, int log_scale, int highbd,
+                    int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob_ptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,10 @@ __global__ void bipred_pack_kernel(const uint8_t* __restrict__ src_plane, uint32
 size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh);
 size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 
+__global__ void quantize_b_batch_kernel(const int32_t* __restrict__ coeff, const svthip_quant_desc* __restrict__ desc, uint32_t n_tu,
+                                        const int16_t* __restrict__ qparams, const int16_t* __restrict__ iscan_pool,
+                                        int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob);
+
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 
 }  // namespace svthip

@@ -194,6 +194,25 @@ int32_t svthip_me_bipred_pack_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, u
     return SVTHIP_OK;
 }
 
+int32_t svthip_quantize_b_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff, const svthip_quant_desc* d_desc, uint32_t n_tu,
+                                    const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_qcoeff, int32_t* d_dqcoeff,
+                                    uint16_t* d_eob, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_tu == 0) return SVTHIP_OK;
+    if (!d_coeff || !d_desc || !d_qparams || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if ((reinterpret_cast<uintptr_t>(d_coeff) | reinterpret_cast<uintptr_t>(d_qcoeff) | reinterpret_cast<uintptr_t>(d_dqcoeff)) & 15u)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "coefficient pools must be 16-byte aligned%s", "");
+    if (reinterpret_cast<uintptr_t>(d_iscan) & 7u) return fail(SVTHIP_ERR_BAD_PARAMETER, "iscan pool must be 8-byte aligned%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint32_t waves = n_tu < 8192u ? n_tu : 8192u;  // grid-stride beyond 2048 workgroups
+    hipLaunchKernelGGL(svthip::quantize_b_batch_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d_coeff, d_desc, n_tu, d_qparams,
+                       d_iscan, d_qcoeff, d_dqcoeff, d_eob);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                         const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
                                         const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,

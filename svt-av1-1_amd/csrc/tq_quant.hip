@@ -1,0 +1,84 @@
+// svt-av1-1_amd/csrc/tq_quant.hip
+//
+// Batched dead-zone quantisation + dequantisation + end-of-block for AV1 transform units, gfx950.
+// Replaces aom_quantize_b{,_32x32,_64x64}_c_II (8-bit path: |coeff|+round clamped to int16) and
+// aom_highbd_quantize_b{,_32x32,_64x64}_c behind av1_quantize_b_facade_II / av1_highbd_quantize_b_facade
+// (Source/Lib/Codec/EbFullLoop.c:46-143, :242-336, :596-664), flat quantisation matrix (the encoder passes
+// qmatrix == NULL, Codec/EbModeDecisionConfigurationProcess.c:525-528).
+//
+// HBM-bound: 16 B per coefficient (4 in + 4 qcoeff + 4 dqcoeff + 2 iscan + params).  One wave per TU; lanes stride the
+// coefficients with 16-byte (4-coefficient) accesses; the pre-scan passes of the reference only skip coefficients inside
+// the dead zone, which the per-coefficient test repeats, so every coefficient is independent and eob is a wave max of
+// (iscan + 1) over non-zero levels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svtav1_hip.h"
+#include "me_kernels.h"
+
+namespace svthip {
+
+namespace {
+__device__ __forceinline__ int32_t rpot(int32_t v, int n) { return n == 0 ? v : ((v + (1 << (n - 1))) >> n); }
+
+__device__ __forceinline__ void quant_one(int32_t c, int ac, const int32_t* zb, const int32_t* rnd, const int16_t* qp, int log_scale,
+                                          int highbd, int32_t& q, int32_t& dq)
+{
+    const int32_t sign = c >> 31;
+    const int32_t abs_c = (c ^ sign) - sign;
+    q = 0;
+    dq = 0;
+    if (abs_c >= zb[ac]) {
+        long long tmp = (long long)abs_c + rnd[ac];
+        if (!highbd) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX); tmp >= 0 here
+        tmp *= 32;
+        const int32_t level = (int32_t)(((((tmp * qp[4 + ac]) >> 16) + tmp) * qp[6 + ac]) >> (16 - log_scale + 5));
+        q = (level ^ sign) - sign;
+        const int32_t abs_dq = (int32_t)((uint32_t)level * (uint32_t)(int32_t)qp[8 + ac]) >> log_scale;
+        dq = (abs_dq ^ sign) - sign;
+    }
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) quantize_b_batch_kernel(const int32_t* __restrict__ coeff,
+                                                               const svthip_quant_desc* __restrict__ desc, uint32_t n_tu,
+                                                               const int16_t* __restrict__ qparams,
+                                                               const int16_t* __restrict__ iscan_pool, int32_t* __restrict__ qcoeff,
+                                                               int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t tu = wave_global; tu < n_tu; tu += n_waves) {
+        const svthip_quant_desc d = desc[tu];
+        const int16_t* qp = qparams + (size_t)d.qparam_index * 10;
+        const int16_t* iscan = iscan_pool + d.iscan_offset;
+        const int log_scale = d.log_scale, highbd = d.highbd;
+        const int32_t zb[2] = {rpot(qp[0], log_scale), rpot(qp[1], log_scale)};
+        const int32_t rnd[2] = {rpot(qp[2], log_scale), rpot(qp[3], log_scale)};
+        const int32_t* cin = coeff + d.coeff_offset;
+        int32_t* qo = qcoeff + d.coeff_offset;
+        int32_t* dqo = dqcoeff + d.coeff_offset;
+        const int n = d.n_coeffs;  // multiple of 16 (4x4 .. 32x32)
+        int last = 0;
+        for (int base = lane * 4; base < n; base += 256) {
+            const int4 c4 = *reinterpret_cast<const int4*>(cin + base);
+            const short4 is4 = *reinterpret_cast<const short4*>(iscan + base);
+            const int32_t cv[4] = {c4.x, c4.y, c4.z, c4.w};
+            const int isv[4] = {is4.x, is4.y, is4.z, is4.w};
+            int32_t qv[4], dqv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                quant_one(cv[k], (base + k) != 0, zb, rnd, qp, log_scale, highbd, qv[k], dqv[k]);
+                if (qv[k] != 0) last = max(last, isv[k] + 1);
+            }
+            *reinterpret_cast<int4*>(qo + base) = make_int4(qv[0], qv[1], qv[2], qv[3]);
+            *reinterpret_cast<int4*>(dqo + base) = make_int4(dqv[0], dqv[1], dqv[2], dqv[3]);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) last = max(last, __shfl_xor(last, m));
+        if (lane == 0) eob[tu] = (uint16_t)last;
+    }
+}
+
+}  // namespace svthip

@@ -78,6 +78,9 @@ def lib() -> C.CDLL:
     L.svthip_me_bipred_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.svthip_quantize_b_batch_dev.restype = C.c_int32
+    L.svthip_quantize_b_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -186,6 +189,13 @@ def _bipred_pack_dev(self, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_re
 Context.bipred_pack_dev = _bipred_pack_dev
 
 
+def _quantize_b_batch_dev(self, d_coeff, d_desc, n_tu, d_qparams, d_iscan, d_qcoeff, d_dqcoeff, d_eob, stream=None):
+    _check(lib().svthip_quantize_b_batch_dev(self._h, d_coeff, d_desc, n_tu, d_qparams, d_iscan, d_qcoeff, d_dqcoeff, d_eob, stream))
+
+
+Context.quantize_b_batch_dev = _quantize_b_batch_dev
+
+
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
     """Descriptors for every SB of a picture the way MotionEstimateLcu derives them
     (Codec/EbMotionEstimation.c:6667-6738): window centred on `centers[sb] = (x, y)` (default 0,0),
@@ -235,6 +245,11 @@ class MeCuResult(C.Structure):
 ME_CU_RESULT_DTYPE = np.dtype([("xMvL0", "<i2"), ("yMvL0", "<i2"), ("xMvL1", "<i2"), ("yMvL1", "<i2"), ("distortion", "<u4", 3),
                                ("direction", "u1", 3), ("totalMeCandidateIndex", "u1")])
 assert ME_CU_RESULT_DTYPE.itemsize == C.sizeof(MeCuResult) == 24
+
+
+QUANT_DESC_DTYPE = np.dtype([("coeff_offset", "<u4"), ("iscan_offset", "<u4"), ("qparam_index", "<u4"), ("n_coeffs", "<u2"),
+                             ("log_scale", "u1"), ("highbd", "u1")])
+assert QUANT_DESC_DTYPE.itemsize == 16
 
 
 class SbOrigin(C.Structure):

@@ -1,0 +1,75 @@
+"""Shared helpers for the transform / quantisation tests."""
+import ctypes as C
+
+import numpy as np
+
+import svtav1_hip
+
+
+def make_qparams(q_dc, q_ac):
+    """One Quants/Dequants row the way av1_build_quantizer builds it (Codec/EbModeDecisionConfigurationProcess.c:417-506):
+    invert_quant -> quant/quant_shift, zbin = ROUND(84*q, 7), round = 64*q >> 7, dequant = q."""
+    out = np.zeros(10, np.int16)
+    for i, q in enumerate((q_dc, q_ac)):
+        l = int(q).bit_length() - 1
+        m = 1 + (1 << (16 + l)) // q
+        out[4 + i] = np.int16(np.uint16((m - (1 << 16)) & 0xffff))
+        out[6 + i] = 1 << (16 - l)
+        out[0 + i] = (84 * q + 64) >> 7
+        out[2 + i] = (64 * q) >> 7
+        out[8 + i] = q
+    return out
+
+
+def random_quant_batch(rng, n_tu, sizes=(16, 64, 256, 1024)):
+    """Random TU batch: returns dict with coeff pool, desc, qparams table, scan/iscan pools."""
+    n_rows = 12
+    qparams = np.stack([make_qparams(int(rng.integers(4, 1337)), int(rng.integers(4, 1829))) for _ in range(n_rows)])
+    scans, iscans, scan_off = [], [], {}
+    off = 0
+    for n in sizes:
+        for v in range(3):
+            sc = rng.permutation(n).astype(np.int16)
+            isc = np.zeros(n, np.int16); isc[sc] = np.arange(n, dtype=np.int16)
+            scan_off[(n, v)] = off
+            scans.append(sc); iscans.append(isc)
+            off += n
+    scan_pool = np.concatenate(scans); iscan_pool = np.concatenate(iscans)
+    desc = np.zeros(n_tu, dtype=svtav1_hip.QUANT_DESC_DTYPE)
+    chunks = []
+    coff = 0
+    for i in range(n_tu):
+        n = int(rng.choice(sizes))
+        row = int(rng.integers(0, n_rows))
+        kind = i % 4
+        q_ac = int(qparams[row, 9])
+        if kind == 0:
+            c = rng.integers(-40, 41, n)
+        elif kind == 1:
+            c = rng.laplace(0, 4 * q_ac, n).astype(np.int64)
+        elif kind == 2:
+            c = rng.integers(-(1 << 17), 1 << 17, n)
+        else:
+            c = np.zeros(n, np.int64); c[rng.integers(0, n, 3)] = rng.integers(-3000, 3000, 3)
+        chunks.append(c.astype(np.int32))
+        desc[i] = (coff, scan_off[(n, int(rng.integers(0, 3)))], row, n, int(rng.integers(0, 3)), int(rng.integers(0, 2)))
+        coff += n
+    return {"coeff": np.concatenate(chunks), "desc": desc, "qparams": qparams, "scan": scan_pool, "iscan": iscan_pool}
+
+
+def oracle_quant_batch(oracle, b):
+    orc = oracle.lib.orc_quantize_b
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    coeff = b["coeff"]
+    q = np.zeros_like(coeff); dq = np.zeros_like(coeff); eob = np.zeros(len(b["desc"]), np.uint16)
+    for i, d in enumerate(b["desc"]):
+        co, so, n = int(d["coeff_offset"]), int(d["iscan_offset"]), int(d["n_coeffs"])
+        e = C.c_uint16(0)
+        qp = np.ascontiguousarray(b["qparams"][int(d["qparam_index"])])
+        c = np.ascontiguousarray(coeff[co:co + n]); sc = np.ascontiguousarray(b["scan"][so:so + n])
+        qq = np.zeros(n, np.int32); dd = np.zeros(n, np.int32)
+        orc(c.ctypes.data, n, qp.ctypes.data, sc.ctypes.data, int(d["log_scale"]), int(d["highbd"]), qq.ctypes.data, dd.ctypes.data,
+            C.addressof(e))
+        q[co:co + n] = qq; dq[co:co + n] = dd; eob[i] = e.value
+    return q, dq, eob
