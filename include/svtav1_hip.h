@@ -242,6 +242,32 @@ int32_t svthip_quantize_b_batch_dev(svthip_ctx *ctx, const int32_t *d_coeff, con
                                     const int16_t *d_qparams, const int16_t *d_iscan, int32_t *d_qcoeff, int32_t *d_dqcoeff,
                                     uint16_t *d_eob, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched forward 2-D transform.  Replaces, per TU, Av1TransformTwoD_{4x4,8x8,16x16,32x32,64x64}_c and
+ * av1_fwd_txfm2d_{WxH}_c (Source/Lib/Codec/EbTransforms.c:3928-4400; signature (int16_t *input, int32_t *output,
+ * uint32_t inputStride, TxType transform_type, uint8_t bit_depth)), i.e. Av1TranformTwoDCore_c (:3701-3780) as configured
+ * by Av1TransformConfig (:3847-3867), which Av1EstimateTransform (:4410-4728) dispatches to.
+ *
+ * One call transforms n_tu units of ONE size tx_width x tx_height (any of the 19 AV1 sizes: 4..64, aspect <= 4:1); the host
+ * groups TUs by size, as the reference's per-size function pointers already do.
+ * d_residual : int16 pool; TU i reads rows at in_offset + r * in_stride (elements), like `input` / `inputStride`.
+ * d_coeff    : int32 pool; TU i writes tx_width * tx_height coefficients, row-major with row stride tx_width, at out_offset
+ *              (multiple of 4) -- the reference's `output` layout before Av1EstimateTransform repacks 64-wide outputs.
+ * tx_type    : TxType 0..15 (Source/Lib/Codec/EbDefinitions.h: DCT_DCT .. H_FLIPADST).  Only combinations for which the
+ *              reference has a 1-D network are defined: ADST/FLIPADST up to 16 points, identity up to 32, 64-point DCT only.
+ * bit_depth  : 8 or 10, as in the reference signature (it only feeds the reference's debug range checks; results are
+ *              bit-identical to the reference for residuals of that depth, |residual| <= 2^bit_depth - 1). */
+typedef struct svthip_txfm_desc {
+    uint32_t in_offset;
+    uint32_t out_offset;
+    uint16_t in_stride;
+    uint8_t tx_type;
+    uint8_t reserved;
+} svthip_txfm_desc;
+
+int32_t svthip_fwd_txfm2d_batch_dev(svthip_ctx *ctx, const int16_t *d_residual, const svthip_txfm_desc *d_desc, uint32_t n_tu,
+                                    uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, int32_t *d_coeff, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

@@ -42,3 +42,238 @@ void orc_quantize_b(const int32_t *coeff, int32_t n_coeffs, const int16_t *qp, c
     }
     *eob_ptr = (uint16_t)(eob + 1);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Forward 2-D transforms (row a16).  Restates Av1TranformTwoDCore_c (EbTransforms.c:3701-3780) with the configuration of
+ * Av1TransformConfig (:3847-3867) and the tables of EbTransforms.h:88-160.  The 1-D networks are written from their
+ * structure (recursive even/odd split for the DCT, layered pair rotations for the ADST), not stage by stage; every
+ * rotation rounds exactly where half_btf (:1292-1299) rounds, so the results are bit-identical to
+ * av1_fdct{4..64}_new (:1314-2762), av1_fadst{4,8,16}_new (:2764-3183) and av1_fidentity*_c.
+ * ------------------------------------------------------------------------------------------------------------------ */
+#include <math.h>
+
+#define ORC_SQRT2 5793 /* NewSqrt2, NewSqrt2Bits = 12 */
+
+static int32_t g_cospi[7][64]; /* [bit-10][j] = round(cos(pi j/128) 2^bit), :1242-1287; checked against the reference table */
+static int g_cospi_ready;
+/* av1_sinpi_arr_data (:1303-1311): round(sqrt(2) sin(j pi/9) 2/3 2^bit), adjusted so that [1]+[2] == [4] */
+static const int32_t g_sinpi[7][5] = {{0, 330, 621, 836, 951},        {0, 660, 1241, 1672, 1901},     {0, 1321, 2482, 3344, 3803},
+                                      {0, 2642, 4964, 6689, 7606},    {0, 5283, 9929, 13377, 15212},  {0, 10566, 19858, 26755, 30424},
+                                      {0, 21133, 39716, 53510, 60849}};
+
+static void cospi_init(void)
+{
+    if (g_cospi_ready) return;
+    for (int b = 0; b < 7; b++)
+        for (int j = 0; j < 64; j++) g_cospi[b][j] = (int32_t)floor(cos(M_PI * j / 128.0) * (double)(1 << (b + 10)) + 0.5);
+    g_cospi_ready = 1;
+}
+const int32_t *orc_cospi_table(int bit) { cospi_init(); return g_cospi[bit - 10]; }
+const int32_t *orc_sinpi_table(int bit) { return g_sinpi[bit - 10]; }
+
+static inline int32_t rs64(int64_t v, int bit) { return (int32_t)((v + ((int64_t)1 << (bit - 1))) >> bit); }
+static inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); } /* int32 product, wraps */
+static inline int32_t hb(int32_t w0, int32_t in0, int32_t w1, int32_t in1, int bit)
+{
+    return rs64((int64_t)wmul(w0, in0) + (int64_t)wmul(w1, in1), bit);
+}
+static int brev(int v, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+static int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+/* mirrored add/sub layer over blocks of `span`: even blocks (lo+hi, lo-hi), odd blocks (hi-lo, hi+lo) */
+static void odd_bfly(int32_t *a, int M, int span)
+{
+    for (int base = 0, blk = 0; base < M; base += span, blk++)
+        for (int t = 0; t < span / 2; t++) {
+            const int i = base + t, j = base + span - 1 - t;
+            const int32_t lo = a[i], hi = a[j];
+            if (!(blk & 1)) { a[i] = lo + hi; a[j] = lo - hi; }
+            else            { a[i] = hi - lo; a[j] = hi + lo; }
+        }
+}
+/* rotation layer j of the odd part: pairs (i, M-1-i) */
+static void odd_rot(int32_t *a, int M, int j, const int32_t *c, int bit)
+{
+    if (j == 1) {
+        for (int i = M / 4; i < M / 2; i++) {
+            const int k = M - 1 - i;
+            const int32_t x = a[i], y = a[k];
+            a[i] = hb(-c[32], x, c[32], y, bit);
+            a[k] = hb(c[32], y, c[32], x, bit);
+        }
+        return;
+    }
+    const int nb = 1 << (j - 2), L = (M / 2) / nb;
+    for (int b = 0; b < nb; b++) {
+        const int al = (16 / nb) * (1 + 4 * brev(b, j - 2));
+        for (int t = L / 4; t < 3 * L / 4; t++) {
+            const int i = b * L + t, k = M - 1 - i;
+            const int32_t x = a[i], y = a[k];
+            if (t < L / 2) { a[i] = hb(-c[al], x, c[64 - al], y, bit);      a[k] = hb(c[al], y, c[64 - al], x, bit); }
+            else           { a[i] = hb(-c[64 - al], x, -c[al], y, bit);     a[k] = hb(c[64 - al], y, -c[al], x, bit); }
+        }
+    }
+}
+/* odd half of an N = 2M point DCT: a[t] = x[M-1-t] - x[M+t]; result y[k] is coefficient 1 + 2 brev(k) */
+static void dct_odd(int32_t *a, int M, const int32_t *c, int bit)
+{
+    const int m = ilog2(M);
+    for (int j = 1; j < m; j++) { odd_rot(a, M, j, c, bit); odd_bfly(a, M, M >> j); }
+    for (int k = 0; k < M / 2; k++) {
+        const int al = (32 / M) * (1 + 4 * brev(k, m - 1)), q = M - 1 - k;
+        const int32_t x = a[k], y = a[q];
+        a[k] = hb(c[64 - al], x, c[al], y, bit);
+        a[q] = hb(c[64 - al], y, -c[al], x, bit);
+    }
+}
+static void fdct_rec(const int32_t *x, int32_t *out, int n, int ostride, const int32_t *c, int bit)
+{
+    if (n == 2) {
+        out[0] = hb(c[32], x[0], c[32], x[1], bit);
+        out[ostride] = hb(-c[32], x[1], c[32], x[0], bit);
+        return;
+    }
+    int32_t s[32] = {0}, a[32];
+    const int M = n / 2, m = ilog2(M);
+    for (int i = 0; i < M; i++) { s[i] = x[i] + x[n - 1 - i]; a[i] = x[M - 1 - i] - x[M + i]; }
+    fdct_rec(s, out, M, 2 * ostride, c, bit);
+    dct_odd(a, M, c, bit);
+    for (int k = 0; k < M; k++) out[(1 + 2 * brev(k, m)) * ostride] = a[k];
+}
+
+static void rotP(int32_t *p, int al, const int32_t *c, int bit)
+{
+    const int32_t x = p[0], y = p[1];
+    p[0] = hb(c[al], x, c[64 - al], y, bit);
+    p[1] = hb(c[64 - al], x, -c[al], y, bit);
+}
+static void rotQ(int32_t *p, int al, const int32_t *c, int bit)
+{
+    const int32_t x = p[0], y = p[1];
+    p[0] = hb(-c[64 - al], x, c[al], y, bit);
+    p[1] = hb(c[al], x, c[64 - al], y, bit);
+}
+static void span_bfly(int32_t *f, int n, int span)
+{
+    for (int base = 0; base < n; base += 2 * span)
+        for (int t = 0; t < span; t++) {
+            const int32_t x = f[base + t], y = f[base + span + t];
+            f[base + t] = x + y;
+            f[base + span + t] = x - y;
+        }
+}
+static void fadst4(const int32_t *x, int32_t *out, int bit)
+{
+    const int32_t *s = g_sinpi[bit - 10];
+    if (!(x[0] | x[1] | x[2] | x[3])) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    const int32_t p = wmul(s[1], x[0]) + wmul(s[2], x[1]) + wmul(s[4], x[3]);
+    const int32_t q = wmul(s[4], x[0]) - wmul(s[1], x[1]) + wmul(s[2], x[3]);
+    const int32_t r = wmul(s[3], x[2]);
+    out[0] = rs64((int32_t)((uint32_t)p + (uint32_t)r), bit);
+    out[1] = rs64(wmul(s[3], x[0] + x[1] - x[3]), bit);
+    out[2] = rs64((int32_t)((uint32_t)q - (uint32_t)r), bit);
+    out[3] = rs64((int32_t)((uint32_t)q - (uint32_t)p + (uint32_t)r), bit);
+}
+static void fadst_n(const int32_t *x, int32_t *out, int n, const int32_t *c, int bit)
+{
+    static const int8_t idx8[8] = {0, 7, 3, 4, 1, 6, 2, 5}, neg8[8] = {0, 1, 1, 0, 1, 0, 0, 1};
+    static const int8_t idx16[16] = {0, 15, 7, 8, 3, 12, 4, 11, 1, 14, 6, 9, 2, 13, 5, 10};
+    static const int8_t neg16[16] = {0, 1, 1, 0, 1, 0, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0};
+    int32_t f[16];
+    for (int i = 0; i < n; i++) {
+        const int32_t v = x[n == 8 ? idx8[i] : idx16[i]];
+        f[i] = (n == 8 ? neg8[i] : neg16[i]) ? -v : v;
+    }
+    for (int g = 0; g < n; g += 4) rotP(f + g + 2, 32, c, bit);
+    span_bfly(f, n, 2);
+    for (int g = 0; g < n; g += 8) { rotP(f + g + 4, 16, c, bit); rotQ(f + g + 6, 16, c, bit); }
+    span_bfly(f, n, 4);
+    if (n == 16) {
+        rotP(f + 8, 8, c, bit); rotP(f + 10, 40, c, bit); rotQ(f + 12, 8, c, bit); rotQ(f + 14, 40, c, bit);
+        span_bfly(f, n, 8);
+    }
+    for (int k = 0; k < n / 2; k++) rotP(f + 2 * k, n == 8 ? 4 + 16 * k : 2 + 8 * k, c, bit);
+    for (int i = 0; i < n / 2; i++) { out[2 * i] = f[2 * i + 1]; out[2 * i + 1] = f[n - 2 - 2 * i]; }
+}
+static void fidentity(const int32_t *x, int32_t *out, int n)
+{
+    for (int i = 0; i < n; i++) switch (n) {
+        case 4:  out[i] = rs64((int64_t)x[i] * ORC_SQRT2, 12); break;
+        case 8:  out[i] = x[i] * 2; break;
+        case 16: out[i] = rs64((int64_t)x[i] * 2 * ORC_SQRT2, 12); break;
+        case 32: out[i] = x[i] * 4; break;
+        default: out[i] = rs64((int64_t)x[i] * 4 * ORC_SQRT2, 12); break;
+    }
+}
+/* 1-D kinds as TX_TYPE_1D: 0 DCT, 1 ADST, 2 FLIPADST (same network, flip applied by the caller), 3 IDTX */
+static void txfm1d(int kind, const int32_t *x, int32_t *out, int n, int bit)
+{
+    const int32_t *c = orc_cospi_table(bit);
+    if (kind == 0) fdct_rec(x, out, n, 1, c, bit);
+    else if (kind == 3) fidentity(x, out, n);
+    else if (n == 4) fadst4(x, out, bit);
+    else fadst_n(x, out, n, c, bit);
+}
+static void shift_array(int32_t *v, int n, int bit) /* av1_round_shift_array_c (:3683-3698) */
+{
+    if (bit == 0) return;
+    for (int i = 0; i < n; i++) v[i] = bit > 0 ? rs64(v[i], bit) : v[i] * (1 << -bit);
+}
+
+static const int8_t k_vtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3}; /* vtx_tab, EbTransforms.h:88 */
+static const int8_t k_htx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2}; /* htx_tab, :93 */
+static const int8_t k_cos_col[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
+static const int8_t k_cos_row[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};
+/* fwd_shift_WxH (:121-139), indexed [log2 w - 2][log2 h - 2] */
+static const int8_t k_shift[5][5][3] = {
+    {{2, 0, 0}, {2, -1, 0}, {2, -1, 0}, {0, 0, 0}, {0, 0, 0}},
+    {{2, -1, 0}, {2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {0, 0, 0}},
+    {{2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {2, -4, 0}, {0, -2, 0}},
+    {{0, 0, 0}, {2, -2, 0}, {2, -4, 0}, {2, -4, 0}, {0, -2, -2}},
+    {{0, 0, 0}, {0, 0, 0}, {2, -4, 0}, {2, -4, -2}, {0, -2, -2}}};
+
+/* returns 0 when (w, h, tx_type) is a combination the reference can run, -1 otherwise (no 1-D network for it) */
+int orc_fwd_txfm2d_valid(int w, int h, int tx_type)
+{
+    if (tx_type < 0 || tx_type > 15) return -1;
+    const int wi = ilog2(w) - 2, hi = ilog2(h) - 2;
+    if (wi < 0 || wi > 4 || hi < 0 || hi > 4 || (1 << (wi + 2)) != w || (1 << (hi + 2)) != h) return -1;
+    if (wi - hi > 2 || hi - wi > 2) return -1;
+    const int kc = k_vtx[tx_type], kr = k_htx[tx_type];
+    if ((kc == 1 || kc == 2) && h > 16) return -1;
+    if ((kr == 1 || kr == 2) && w > 16) return -1;
+    if (kc == 3 && h > 32) return -1;
+    if (kr == 3 && w > 32) return -1;
+    return 0;
+}
+
+void orc_fwd_txfm2d(const int16_t *input, int32_t stride, int w, int h, int tx_type, int32_t *output)
+{
+    const int wi = ilog2(w) - 2, hi = ilog2(h) - 2;
+    const int kc = k_vtx[tx_type], kr = k_htx[tx_type];
+    const int ud = (kc == 2), lr = (kr == 2); /* get_flip_cfg (:3782-3820) */
+    const int8_t *sh = k_shift[wi][hi];
+    const int cos_col = k_cos_col[wi][hi], cos_row = k_cos_row[wi][hi];
+    const int rect = wi > hi ? wi - hi : hi - wi;
+    int32_t col[64], tmp[64];
+    int32_t *buf = (int32_t *)__builtin_alloca(sizeof(int32_t) * (size_t)(w * h));
+    for (int c = 0; c < w; c++) {
+        for (int r = 0; r < h; r++) col[r] = input[(ud ? h - 1 - r : r) * stride + c];
+        shift_array(col, h, -sh[0]);
+        txfm1d(kc, col, tmp, h, cos_col);
+        shift_array(tmp, h, -sh[1]);
+        for (int r = 0; r < h; r++) buf[r * w + (lr ? w - 1 - c : c)] = tmp[r];
+    }
+    for (int r = 0; r < h; r++) {
+        int32_t *o = output + r * w;
+        txfm1d(kr, buf + r * w, o, w, cos_row);
+        shift_array(o, w, -sh[2]);
+        if (rect == 1)
+            for (int c = 0; c < w; c++) o[c] = rs64((int64_t)o[c] * ORC_SQRT2, 12);
+    }
+}

@@ -45,6 +45,11 @@ __global__ void quantize_b_batch_kernel(const int32_t* __restrict__ coeff, const
                                         const int16_t* __restrict__ qparams, const int16_t* __restrict__ iscan_pool,
                                         int32_t* __restrict__ qcoeff, int32_t* __restrict__ dqcoeff, uint16_t* __restrict__ eob);
 
+bool fwd_txfm2d_size_valid(int w, int h);
+bool fwd_txfm2d_type_valid(int w, int h, int tx_type);
+hipError_t launch_fwd_txfm2d(const int16_t* residual, const svthip_txfm_desc* desc, uint32_t n_tu, int w, int h, int32_t* coeff,
+                             hipStream_t s);
+
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 
 }  // namespace svthip

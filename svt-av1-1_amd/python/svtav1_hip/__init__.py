@@ -81,6 +81,9 @@ def lib() -> C.CDLL:
     L.svthip_quantize_b_batch_dev.restype = C.c_int32
     L.svthip_quantize_b_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svthip_fwd_txfm2d_batch_dev.restype = C.c_int32
+    L.svthip_fwd_txfm2d_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -196,6 +199,13 @@ def _quantize_b_batch_dev(self, d_coeff, d_desc, n_tu, d_qparams, d_iscan, d_qco
 Context.quantize_b_batch_dev = _quantize_b_batch_dev
 
 
+def _fwd_txfm2d_batch_dev(self, d_residual, d_desc, n_tu, tx_width, tx_height, bit_depth, d_coeff, stream=None):
+    _check(lib().svthip_fwd_txfm2d_batch_dev(self._h, d_residual, d_desc, n_tu, tx_width, tx_height, bit_depth, d_coeff, stream))
+
+
+Context.fwd_txfm2d_batch_dev = _fwd_txfm2d_batch_dev
+
+
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
     """Descriptors for every SB of a picture the way MotionEstimateLcu derives them
     (Codec/EbMotionEstimation.c:6667-6738): window centred on `centers[sb] = (x, y)` (default 0,0),
@@ -250,6 +260,27 @@ assert ME_CU_RESULT_DTYPE.itemsize == C.sizeof(MeCuResult) == 24
 QUANT_DESC_DTYPE = np.dtype([("coeff_offset", "<u4"), ("iscan_offset", "<u4"), ("qparam_index", "<u4"), ("n_coeffs", "<u2"),
                              ("log_scale", "u1"), ("highbd", "u1")])
 assert QUANT_DESC_DTYPE.itemsize == 16
+
+
+TXFM_DESC_DTYPE = np.dtype([("in_offset", "<u4"), ("out_offset", "<u4"), ("in_stride", "<u2"), ("tx_type", "u1"), ("reserved", "u1")])
+assert TXFM_DESC_DTYPE.itemsize == 12
+
+# the 19 AV1 transform sizes (width, height), TxSize order (Codec/EbDefinitions.h)
+TX_SIZES_WH = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64),
+               (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+_VTX = [0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3]  # vtx_tab / htx_tab (Codec/EbTransforms.h:88-97): 0 DCT 1 ADST 2 FLIPADST 3 IDTX
+_HTX = [0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2]
+
+
+def valid_tx_types(w: int, h: int):
+    """TxTypes for which the reference has 1-D networks at this size (ADST up to 16 points, identity up to 32, 64 DCT only)."""
+    out = []
+    for t in range(16):
+        kc, kr = _VTX[t], _HTX[t]
+        if (kc in (1, 2) and h > 16) or (kr in (1, 2) and w > 16) or (kc == 3 and h > 32) or (kr == 3 and w > 32):
+            continue
+        out.append(t)
+    return out
 
 
 class SbOrigin(C.Structure):

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import svtav1_hip
-from tq_util import oracle_quant_batch, random_quant_batch
+from tq_util import oracle_quant_batch, oracle_txfm_batch, random_quant_batch, random_txfm_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -30,3 +30,36 @@ def test_quantize_batch_matches_oracle(hip_ctx, oracle, n_tu):
     assert np.array_equal(d_q.cpu().numpy(), q_o)
     assert np.array_equal(d_dq.cpu().numpy(), dq_o)
     assert np.array_equal(d_eob.cpu().numpy().view(np.uint16), eob_o)
+
+
+@pytest.mark.parametrize("size", svtav1_hip.TX_SIZES_WH)
+@pytest.mark.parametrize("bit_depth", [8, 10])
+def test_fwd_txfm2d_batch_matches_oracle(hip_ctx, oracle, size, bit_depth):
+    """Every AV1 transform size, every transform type the reference defines for it, 8- and 10-bit residual ranges."""
+    torch = pytest.importorskip("torch")
+    w, h = size
+    n_tu = 333 if w * h <= 1024 else 97       # not a multiple of the TUs-per-wave group: exercises the ragged tail
+    rng = np.random.default_rng(w * 1000 + h * 10 + bit_depth)
+    b = random_txfm_batch(rng, n_tu, w, h, bit_depth)
+    ref = oracle_txfm_batch(oracle, b)
+    d_res, d_desc = _dev(b["residual"]), _dev(b["desc"])
+    d_out = torch.full((n_tu * w * h,), 0x5a5a5a5a, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.fwd_txfm2d_batch_dev(d_res.data_ptr(), d_desc.data_ptr(), n_tu, w, h, bit_depth, d_out.data_ptr())
+    hip_ctx.synchronize()
+    got = d_out.cpu().numpy()
+    bad = np.flatnonzero(got != ref)
+    assert bad.size == 0, (size, bit_depth, bad[:8], got[bad[:8]], ref[bad[:8]], b["desc"][bad[0] // (w * h)])
+
+
+def test_fwd_txfm2d_rejects_bad_arguments(hip_ctx):
+    torch = pytest.importorskip("torch")
+    buf = torch.zeros(4096, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 4, 64, 8, buf.data_ptr())    # 16:1 is not an AV1 size
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 12, 12, 8, buf.data_ptr())
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 8, 8, 12, buf.data_ptr())
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 8, 8, 8, buf.data_ptr() + 4)  # misaligned output

@@ -69,3 +69,69 @@ def test_quantize_matches_reference(oracle, reftq, fn):
         assert np.array_equal(oq, rq), (name, trial)
         assert np.array_equal(odq, rdq), (name, trial)
         assert oeob.value == reob.value, (name, trial)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# forward transforms
+# ---------------------------------------------------------------------------------------------------------------------
+def ref_fwd_name(w, h):
+    return f"Av1TransformTwoD_{w}x{h}_c" if w == h else f"av1_fwd_txfm2d_{w}x{h}_c"
+
+
+FWD_SIZES = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64),
+             (64, 32), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+def test_trig_tables_match_reference(oracle, reftq):
+    """The oracle computes cos tables from the closed form; the reference holds them as data (EbTransforms.c:1242-1311)."""
+    ref_cos = (C.c_int32 * (7 * 64)).in_dll(reftq, "av1_cospi_arr_data")
+    ref_sin = (C.c_int32 * (7 * 5)).in_dll(reftq, "av1_sinpi_arr_data")
+    oracle.lib.orc_cospi_table.restype = C.POINTER(C.c_int32)
+    oracle.lib.orc_sinpi_table.restype = C.POINTER(C.c_int32)
+    for bit in range(10, 17):
+        oc = oracle.lib.orc_cospi_table(bit)
+        os_ = oracle.lib.orc_sinpi_table(bit)
+        assert [oc[j] for j in range(64)] == list(ref_cos[(bit - 10) * 64:(bit - 9) * 64])
+        assert [os_[j] for j in range(5)] == list(ref_sin[(bit - 10) * 5:(bit - 9) * 5])
+
+
+def fwd_inputs(rng, w, h, kind, bd):
+    lim = (1 << bd) - 1
+    if kind == 0:
+        return rng.integers(-lim, lim + 1, (h, w))
+    if kind == 1:
+        return rng.choice([-lim, lim], (h, w))                      # worst-case magnitude
+    if kind == 2:
+        x = np.zeros((h, w), np.int64); x[rng.integers(0, h), rng.integers(0, w)] = int(rng.integers(-lim, lim + 1)); return x
+    if kind == 3:
+        yy, xx = np.mgrid[0:h, 0:w]
+        return np.clip((40 * np.sin(xx / 3.0) + 25 * np.cos(yy / 5.0) + rng.integers(-4, 5, (h, w))).astype(np.int64), -lim, lim)
+    return np.zeros((h, w), np.int64)
+
+
+@pytest.mark.parametrize("size", FWD_SIZES)
+def test_fwd_txfm2d_matches_reference(oracle, reftq, size):
+    w, h = size
+    f = getattr(reftq, ref_fwd_name(w, h))
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint8]
+    orc = oracle.lib.orc_fwd_txfm2d
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    oracle.lib.orc_fwd_txfm2d_valid.restype = C.c_int
+    rng = np.random.default_rng(w * 131 + h)
+    n_checked = 0
+    for tx_type in range(16):
+        if oracle.lib.orc_fwd_txfm2d_valid(w, h, tx_type) != 0:
+            continue
+        for trial in range(10):
+            bd = 10 if trial >= 5 else 8
+            stride = w + int(rng.integers(0, 9))
+            x = np.zeros((h, stride), np.int16)
+            x[:, :w] = fwd_inputs(rng, w, h, trial % 5, bd)
+            ro = np.full(h * w, 12345, np.int32); oo = np.full(h * w, 54321, np.int32)
+            f(x.ctypes.data, ro.ctypes.data, stride, tx_type, bd)
+            orc(x.ctypes.data, stride, w, h, tx_type, oo.ctypes.data)
+            assert np.array_equal(oo, ro), (w, h, tx_type, trial, np.flatnonzero(oo != ro)[:8])
+            n_checked += 1
+    assert n_checked >= 10

@@ -73,3 +73,34 @@ def oracle_quant_batch(oracle, b):
             C.addressof(e))
         q[co:co + n] = qq; dq[co:co + n] = dd; eob[i] = e.value
     return q, dq, eob
+
+
+def random_txfm_batch(rng, n_tu, w, h, bit_depth=8, pic_w=256, pic_h=128):
+    """TUs of one size scattered over a residual picture (stride = picture width, like the encoder's residual buffers)."""
+    lim = (1 << bit_depth) - 1
+    yy, xx = np.mgrid[0:pic_h, 0:pic_w]
+    smooth = 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0)
+    res = np.clip(smooth + rng.normal(0, 12, (pic_h, pic_w)), -lim, lim).astype(np.int16)
+    res[: pic_h // 4] = rng.integers(-lim, lim + 1, (pic_h // 4, pic_w))     # full-range noise band
+    res[pic_h // 4: pic_h // 4 + 8] = rng.choice([-lim, lim], (8, pic_w))    # worst-case magnitudes
+    res[-8:] = 0                                                               # all-zero TUs
+    types = svtav1_hip.valid_tx_types(w, h)
+    desc = np.zeros(n_tu, dtype=svtav1_hip.TXFM_DESC_DTYPE)
+    for i in range(n_tu):
+        x0 = int(rng.integers(0, (pic_w - w) // 4 + 1)) * 4
+        y0 = int(rng.integers(0, pic_h - h + 1))
+        desc[i] = (y0 * pic_w + x0, i * w * h, pic_w, types[int(rng.integers(0, len(types)))], 0)
+    return {"residual": res.reshape(-1), "desc": desc, "w": w, "h": h, "bit_depth": bit_depth}
+
+
+def oracle_txfm_batch(oracle, b):
+    orc = oracle.lib.orc_fwd_txfm2d
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    w, h = b["w"], b["h"]
+    res = b["residual"]
+    out = np.zeros(len(b["desc"]) * w * h, np.int32)
+    for d in b["desc"]:
+        o = int(d["out_offset"])
+        orc(res.ctypes.data + 2 * int(d["in_offset"]), int(d["in_stride"]), w, h, int(d["tx_type"]), out.ctypes.data + 4 * o)
+    return out
