@@ -268,6 +268,30 @@ typedef struct svthip_txfm_desc {
 int32_t svthip_fwd_txfm2d_batch_dev(svthip_ctx *ctx, const int16_t *d_residual, const svthip_txfm_desc *d_desc, uint32_t n_tu,
                                     uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, int32_t *d_coeff, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched inverse 2-D transform + reconstruction.  Replaces, per TU, av1_inv_txfm2d_add_{WxH}_c
+ * (Source/Lib/Codec/EbTransforms.c:7714-7900; (const int32_t *input, uint16_t *output, int32_t stride, TxType tx_type,
+ * [TxSize, [eob,]] int32_t bd)), which Av1InvTransformRecon / Av1InvTransformRecon8bit (:8344-8399) reach through
+ * highbd_inv_txfm_add (:8252-8320) / av1_inv_txfm_add_c (:8321-8340, the 8-bit plane is widened, reconstructed and
+ * narrowed again -- equivalent to reconstructing the 8-bit plane directly, which is what recon_16bit = 0 does).
+ *
+ * One call handles n_tu units of ONE size.  d_coeff: int32 pool of dequantised coefficients; TU i reads
+ * min(W,32) x min(H,32) values, row stride min(W,32), at coeff_offset (multiple of 4) -- 64-point dimensions are stored
+ * packed like the reference's input (:7736-7760).  d_recon: the prediction plane (uint8 when recon_16bit == 0, else
+ * uint16), updated in place at recon_offset + r * recon_stride (elements) with clip(pred + residual) as the reference does.
+ * TUs of one call must not overlap in d_recon. */
+typedef struct svthip_itxfm_desc {
+    uint32_t coeff_offset;
+    uint32_t recon_offset;
+    uint16_t recon_stride;
+    uint8_t tx_type;
+    uint8_t reserved;
+} svthip_itxfm_desc;
+
+int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx *ctx, const int32_t *d_coeff, const svthip_itxfm_desc *d_desc, uint32_t n_tu,
+                                        uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, uint32_t recon_16bit,
+                                        void *d_recon, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

@@ -277,3 +277,170 @@ void orc_fwd_txfm2d(const int16_t *input, int32_t stride, int w, int h, int tx_t
             for (int c = 0; c < w; c++) o[c] = rs64((int64_t)o[c] * ORC_SQRT2, 12);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Inverse 2-D transforms + reconstruction (row a17).  Restates inv_txfm2d_add_c (EbTransforms.c:7617-7700) behind
+ * av1_inv_txfm2d_add_{WxH}_c (:7714-7900) as configured by av1_get_inv_txfm_cfg (:7590-7616): rows first (input clamped to
+ * bd+8 bits, 2:1 rectangles pre-scaled by 1/sqrt(2)), round shift, columns (input clamped to max(bd+6,16) bits), round
+ * shift by 4, flips, add to the prediction and clip.  Every add/sub stage of the inverse DCT/ADST networks clamps to the
+ * pass's stage range (av1_gen_inv_stage_range, :4841-4893: bd+8 for rows, 16 for columns at 8/10 bit); the rotations are
+ * the transposes of the forward ones.  64-point dimensions read a 32-wide/32-high packed input, rest zero (:7736-7760).
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define ORC_INV_SQRT2 2896 /* NewInvSqrt2 */
+
+static inline int32_t clampv(int32_t v, int bit) /* clamp_value (:4895-4900) */
+{
+    if (bit <= 0) return v;
+    const int64_t mx = ((int64_t)1 << (bit - 1)) - 1, mn = -((int64_t)1 << (bit - 1));
+    return (int32_t)(v < mn ? mn : (v > mx ? mx : v));
+}
+static inline int32_t addc(int32_t a, int32_t b, int R) { return clampv((int32_t)((uint32_t)a + (uint32_t)b), R); }
+static inline int32_t subc(int32_t a, int32_t b, int R) { return clampv((int32_t)((uint32_t)a - (uint32_t)b), R); }
+
+static void odd_bfly_c(int32_t *a, int M, int span, int R)
+{
+    for (int base = 0, blk = 0; base < M; base += span, blk++)
+        for (int t = 0; t < span / 2; t++) {
+            const int i = base + t, j = base + span - 1 - t;
+            const int32_t lo = a[i], hi = a[j];
+            if (!(blk & 1)) { a[i] = addc(lo, hi, R); a[j] = subc(lo, hi, R); }
+            else            { a[i] = subc(hi, lo, R); a[j] = addc(hi, lo, R); }
+        }
+}
+static void idct_rec(const int32_t *x, int xs, int32_t *out, int n, const int32_t *c, int bit, int R)
+{
+    if (n == 2) {
+        out[0] = hb(c[32], x[0], c[32], x[xs], bit);
+        out[1] = hb(c[32], x[0], -c[32], x[xs], bit);
+        return;
+    }
+    int32_t e[32] = {0}, d[32];
+    const int M = n / 2, m = ilog2(M);
+    idct_rec(x, 2 * xs, e, M, c, bit, R);
+    for (int k = 0; k < M; k++) d[k] = x[(1 + 2 * brev(k, m)) * xs];
+    for (int k = 0; k < M / 2; k++) { /* transposed final rotations of the forward odd part */
+        const int al = (32 / M) * (1 + 4 * brev(k, m - 1)), q = M - 1 - k;
+        const int32_t u = d[k], v = d[q];
+        d[k] = hb(c[64 - al], u, -c[al], v, bit);
+        d[q] = hb(c[al], u, c[64 - al], v, bit);
+    }
+    for (int j = m - 1; j >= 1; j--) { odd_bfly_c(d, M, M >> j, R); odd_rot(d, M, j, c, bit); }
+    for (int i = 0; i < M; i++) { out[i] = addc(e[i], d[M - 1 - i], R); out[n - 1 - i] = subc(e[i], d[M - 1 - i], R); }
+}
+static void span_bfly_c(int32_t *f, int n, int span, int R)
+{
+    for (int base = 0; base < n; base += 2 * span)
+        for (int t = 0; t < span; t++) {
+            const int32_t x = f[base + t], y = f[base + span + t];
+            f[base + t] = addc(x, y, R);
+            f[base + span + t] = subc(x, y, R);
+        }
+}
+static void iadst4(const int32_t *x, int32_t *out, int bit)
+{
+    const int32_t *s = g_sinpi[bit - 10];
+    if (!(x[0] | x[1] | x[2] | x[3])) { out[0] = out[1] = out[2] = out[3] = 0; return; }
+    const uint32_t A = (uint32_t)wmul(s[1], x[0]) + (uint32_t)wmul(s[4], x[2]) + (uint32_t)wmul(s[2], x[3]);
+    const uint32_t B = (uint32_t)wmul(s[2], x[0]) - (uint32_t)wmul(s[1], x[2]) - (uint32_t)wmul(s[4], x[3]);
+    const uint32_t Cc = (uint32_t)wmul(s[3], x[1]);
+    const uint32_t x023 = (uint32_t)x[0] - (uint32_t)x[2] + (uint32_t)x[3];
+    out[0] = rs64((int32_t)(A + Cc), bit);
+    out[1] = rs64((int32_t)(B + Cc), bit);
+    out[2] = rs64(wmul(s[3], (int32_t)x023), bit);
+    out[3] = rs64((int32_t)(A + B - Cc), bit);
+}
+static void iadst_n(const int32_t *x, int32_t *out, int n, const int32_t *c, int bit, int R)
+{
+    static const int8_t o8[8] = {0, 4, 6, 2, 3, 7, 5, 1};
+    static const int8_t o16[16] = {0, 8, 12, 4, 6, 14, 10, 2, 3, 11, 15, 7, 5, 13, 9, 1};
+    int32_t f[16];
+    for (int i = 0; i < n / 2; i++) { f[2 * i] = x[n - 1 - 2 * i]; f[2 * i + 1] = x[2 * i]; }
+    for (int k = 0; k < n / 2; k++) rotP(f + 2 * k, n == 8 ? 4 + 16 * k : 2 + 8 * k, c, bit);
+    span_bfly_c(f, n, n / 2, R);
+    if (n == 16) {
+        rotP(f + 8, 8, c, bit); rotP(f + 10, 40, c, bit); rotQ(f + 12, 8, c, bit); rotQ(f + 14, 40, c, bit);
+        span_bfly_c(f, n, 4, R);
+    }
+    for (int g = 0; g < n; g += 8) { rotP(f + g + 4, 16, c, bit); rotQ(f + g + 6, 16, c, bit); }
+    span_bfly_c(f, n, 2, R);
+    for (int g = 0; g < n; g += 4) rotP(f + g + 2, 32, c, bit);
+    for (int i = 0; i < n; i++) {
+        const int32_t v = f[n == 8 ? o8[i] : o16[i]];
+        out[i] = (i & 1) ? (int32_t)(0u - (uint32_t)v) : v;
+    }
+}
+static void iidentity(const int32_t *x, int32_t *out, int n)
+{
+    for (int i = 0; i < n; i++) switch (n) {
+        case 4:  out[i] = rs64((int64_t)ORC_SQRT2 * x[i], 12); break;
+        case 8:  out[i] = (int32_t)((int64_t)x[i] * 2); break;
+        case 16: out[i] = rs64((int64_t)ORC_SQRT2 * 2 * x[i], 12); break;
+        case 32: out[i] = (int32_t)((int64_t)x[i] * 4); break;
+        default: out[i] = rs64((int64_t)ORC_SQRT2 * 4 * x[i], 12); break;
+    }
+}
+static void itxfm1d(int kind, const int32_t *x, int32_t *out, int n, int bit, int R)
+{
+    const int32_t *c = orc_cospi_table(bit);
+    if (kind == 0) idct_rec(x, 1, out, n, c, bit, R);
+    else if (kind == 3) iidentity(x, out, n);
+    else if (n == 4) iadst4(x, out, bit);
+    else iadst_n(x, out, n, c, bit, R);
+}
+/* inv_shift_WxH[0] (EbTransforms.h:255-273), indexed [log2 w - 2][log2 h - 2]; shift[1] is -4 for every size */
+static const int8_t k_inv_shift0[5][5] = {{0, 0, -1, 0, 0}, {0, -1, -1, -2, 0}, {-1, -1, -2, -1, -2}, {0, -2, -1, -2, -1}, {0, 0, -2, -1, -2}};
+
+/* residual core: input rows at `in_stride`, only the top-left min(w,32) x min(h,32) coefficients are read (the rest of a
+ * 64-point dimension is zero, :7736-7760 / :7455-7476); res = w x h residuals (after the final round shift and flips) */
+static void inv_txfm2d_core(const int32_t *input, int32_t in_stride, int w, int h, int tx_type, int bd, int32_t *res)
+{
+    const int wi = ilog2(w) - 2, hi = ilog2(h) - 2;
+    const int kc = k_vtx[tx_type], kr = k_htx[tx_type];
+    const int ud = (kc == 2), lr = (kr == 2);
+    const int rect = wi > hi ? wi - hi : hi - wi;
+    const int sh0 = k_inv_shift0[wi][hi];
+    const int R_row = bd + 8, R_col = (bd + 6 > 16) ? bd + 6 : 16;
+    const int win = w > 32 ? 32 : w, hin = h > 32 ? 32 : h;
+    int32_t tin[64], tout[64];
+    int32_t *buf = (int32_t *)__builtin_alloca(sizeof(int32_t) * (size_t)(w * h));
+    for (int r = 0; r < h; r++) {
+        for (int c = 0; c < w; c++) {
+            const int32_t v = (r < hin && c < win) ? input[r * in_stride + c] : 0;
+            tin[c] = clampv(rect == 1 ? rs64((int64_t)v * ORC_INV_SQRT2, 12) : v, bd + 8);
+        }
+        itxfm1d(kr, tin, buf + r * w, w, 12, R_row);
+        shift_array(buf + r * w, w, -sh0);
+    }
+    for (int c = 0; c < w; c++) {
+        for (int r = 0; r < h; r++) tin[r] = clampv(buf[r * w + (lr ? w - 1 - c : c)], R_col);
+        itxfm1d(kc, tin, tout, h, 12, R_col);
+        shift_array(tout, h, 4);
+        for (int r = 0; r < h; r++) res[r * w + c] = tout[ud ? h - 1 - r : r];
+    }
+}
+
+/* Av1InverseTransformTwoD_{NxN}_c (:7343-7500): residual out, no prediction */
+void orc_inv_txfm2d(const int32_t *input, int32_t in_stride, int w, int h, int tx_type, int bd, int32_t *output, int32_t out_stride)
+{
+    int32_t *res = (int32_t *)__builtin_alloca(sizeof(int32_t) * (size_t)(w * h));
+    inv_txfm2d_core(input, in_stride, w, h, tx_type, bd, res);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) output[r * out_stride + c] = res[r * w + c];
+}
+
+/* av1_inv_txfm2d_add_{WxH}_c: input min(w,32) x min(h,32) coefficients, row stride min(w,32); output: uint16 prediction,
+ * reconstructed in place */
+void orc_inv_txfm2d_add(const int32_t *input, uint16_t *output, int32_t stride, int w, int h, int tx_type, int bd)
+{
+    int32_t *res = (int32_t *)__builtin_alloca(sizeof(int32_t) * (size_t)(w * h));
+    inv_txfm2d_core(input, w > 32 ? 32 : w, w, h, tx_type, bd, res);
+    const int64_t int_max = ((int64_t)1 << (7 + bd)) - 1 + (914 << (bd - 7)); /* check_range (:7135-7147) */
+    const int pix_max = (1 << bd) - 1;
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            int64_t t = res[r * w + c];
+            t = t < -int_max - 1 ? -int_max - 1 : (t > int_max ? int_max : t);
+            const int32_t p = (int32_t)output[r * stride + c] + (int32_t)t;
+            output[r * stride + c] = (uint16_t)(p < 0 ? 0 : (p > pix_max ? pix_max : p));
+        }
+}

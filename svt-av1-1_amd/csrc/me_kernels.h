@@ -50,6 +50,9 @@ bool fwd_txfm2d_type_valid(int w, int h, int tx_type);
 hipError_t launch_fwd_txfm2d(const int16_t* residual, const svthip_txfm_desc* desc, uint32_t n_tu, int w, int h, int32_t* coeff,
                              hipStream_t s);
 
+hipError_t launch_inv_txfm2d_add(const int32_t* coeff, const svthip_itxfm_desc* desc, uint32_t n_tu, int w, int h, int bd,
+                                 void* recon, int recon_16bit, hipStream_t s);
+
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 
 }  // namespace svthip

@@ -228,6 +228,25 @@ int32_t svthip_fwd_txfm2d_batch_dev(svthip_ctx* ctx, const int16_t* d_residual, 
     return SVTHIP_OK;
 }
 
+int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff, const svthip_itxfm_desc* d_desc, uint32_t n_tu,
+                                        uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, uint32_t recon_16bit,
+                                        void* d_recon, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
+    if (bit_depth != 8 && bit_depth != 10) return fail(SVTHIP_ERR_BAD_PARAMETER, "bit_depth must be 8 or 10%s (got %d)", "", (int)bit_depth);
+    if (bit_depth == 10 && !recon_16bit) return fail(SVTHIP_ERR_BAD_PARAMETER, "10-bit reconstruction needs a 16-bit plane%s", "");
+    if (n_tu == 0) return SVTHIP_OK;
+    if (!d_coeff || !d_desc || !d_recon) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (reinterpret_cast<uintptr_t>(d_coeff) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "coefficient pool must be 16-byte aligned%s", "");
+    if (recon_16bit && (reinterpret_cast<uintptr_t>(d_recon) & 1u)) return fail(SVTHIP_ERR_BAD_PARAMETER, "16-bit plane must be 2-byte aligned%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(svthip::launch_inv_txfm2d_add(d_coeff, d_desc, n_tu, (int)tx_width, (int)tx_height, (int)bit_depth, d_recon,
+                                          recon_16bit ? 1 : 0, s));
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                         const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
                                         const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,

@@ -27,33 +27,7 @@ namespace svthip {
 
 namespace {
 
-#include "tq_cospi.inc"
-
-constexpr int cbrev(int v, int bits)
-{
-    int r = 0;
-    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
-    return r;
-}
-constexpr int clog2(int n)
-{
-    int l = 0;
-    while ((1 << l) < n) l++;
-    return l;
-}
-
-template <int BIT>
-__device__ __forceinline__ int32_t hb(int32_t w0, int32_t a, int32_t w1, int32_t b)
-{
-    const int64_t s = (int64_t)w0 * a + (int64_t)w1 * b + ((int64_t)1 << (BIT - 1));
-    return (int32_t)(s >> BIT);
-}
-template <int BIT>
-__device__ __forceinline__ int32_t rs(int64_t v)
-{
-    return (int32_t)((v + ((int64_t)1 << (BIT - 1))) >> BIT);
-}
-#define COS(j) (kCospi[BIT - 10][(j)])
+#include "tq_txfm_common.h"
 
 // ---- DCT: recursive even/odd split; the odd half is rotation layers interleaved with mirrored add/sub layers ----------
 template <int M, int SPAN>
@@ -68,32 +42,6 @@ __device__ __forceinline__ void odd_bfly(int32_t* a)
             if (((base / SPAN) & 1) == 0) { a[i] = lo + hi; a[j] = lo - hi; }
             else                          { a[i] = hi - lo; a[j] = hi + lo; }
         }
-}
-template <int M, int J, int BIT>
-__device__ __forceinline__ void odd_rot(int32_t* a)
-{
-    if constexpr (J == 1) {
-#pragma unroll
-        for (int i = M / 4; i < M / 2; i++) {
-            const int k = M - 1 - i;
-            const int32_t x = a[i], y = a[k];
-            a[i] = hb<BIT>(-COS(32), x, COS(32), y);
-            a[k] = hb<BIT>(COS(32), y, COS(32), x);
-        }
-    } else {
-        constexpr int NB = 1 << (J - 2), L = (M / 2) / NB;
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int al = (16 / NB) * (1 + 4 * cbrev(b, J - 2));
-#pragma unroll
-            for (int t = L / 4; t < 3 * L / 4; t++) {
-                const int i = b * L + t, k = M - 1 - i;
-                const int32_t x = a[i], y = a[k];
-                if (t < L / 2) { a[i] = hb<BIT>(-COS(al), x, COS(64 - al), y);      a[k] = hb<BIT>(COS(al), y, COS(64 - al), x); }
-                else           { a[i] = hb<BIT>(-COS(64 - al), x, -COS(al), y);     a[k] = hb<BIT>(COS(64 - al), y, -COS(al), x); }
-            }
-        }
-    }
 }
 template <int M, int J, int BIT>
 __device__ __forceinline__ void odd_layers(int32_t* a)
@@ -139,20 +87,6 @@ __device__ __forceinline__ void fdct(const int32_t* x, int32_t* out)
 }
 
 // ---- ADST ---------------------------------------------------------------------------------------------------------------
-template <int BIT>
-__device__ __forceinline__ void rot_p(int32_t* p, int al)
-{
-    const int32_t x = p[0], y = p[1];
-    p[0] = hb<BIT>(COS(al), x, COS(64 - al), y);
-    p[1] = hb<BIT>(COS(64 - al), x, -COS(al), y);
-}
-template <int BIT>
-__device__ __forceinline__ void rot_q(int32_t* p, int al)
-{
-    const int32_t x = p[0], y = p[1];
-    p[0] = hb<BIT>(-COS(64 - al), x, COS(al), y);
-    p[1] = hb<BIT>(COS(al), x, COS(64 - al), y);
-}
 template <int N, int SPAN>
 __device__ __forceinline__ void span_bfly(int32_t* f)
 {
@@ -230,7 +164,6 @@ __device__ __forceinline__ void fidentity(const int32_t* x, int32_t* out)
         else out[i] = x[i] * 4;
     }
 }
-#undef COS
 
 // kind: TX_TYPE_1D (0 DCT, 1 ADST, 2 FLIPADST, 3 IDTX)
 template <int N, int BIT>
@@ -255,8 +188,6 @@ __device__ __forceinline__ int32_t shift_val(int32_t v)  // av1_round_shift_arra
     else return rs<-SH>((int64_t)v);
 }
 
-__device__ constexpr int8_t kVtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};
-__device__ constexpr int8_t kHtx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};
 
 constexpr int kCosCol[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
 constexpr int kCosRow[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};

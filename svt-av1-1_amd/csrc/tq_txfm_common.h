@@ -1,0 +1,76 @@
+// svt-av1-1_amd/csrc/tq_txfm_common.h -- device helpers shared by the forward and inverse transform kernels.
+// Included inside namespace svthip { namespace { ... } } of each .hip file.
+#pragma once
+
+#include "tq_cospi.inc"
+
+constexpr int cbrev(int v, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+constexpr int clog2(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return l;
+}
+
+template <int BIT>
+__device__ __forceinline__ int32_t hb(int32_t w0, int32_t a, int32_t w1, int32_t b)
+{
+    const int64_t s = (int64_t)w0 * a + (int64_t)w1 * b + ((int64_t)1 << (BIT - 1));
+    return (int32_t)(s >> BIT);
+}
+template <int BIT>
+__device__ __forceinline__ int32_t rs(int64_t v)
+{
+    return (int32_t)((v + ((int64_t)1 << (BIT - 1))) >> BIT);
+}
+#define COS(j) (kCospi[BIT - 10][(j)])
+
+// rotation layer J of the odd half of a DCT (pairs (i, M-1-i)); the 2x2 blocks are symmetric, so the inverse network
+// applies the same layer
+template <int M, int J, int BIT>
+__device__ __forceinline__ void odd_rot(int32_t* a)
+{
+    if constexpr (J == 1) {
+#pragma unroll
+        for (int i = M / 4; i < M / 2; i++) {
+            const int k = M - 1 - i;
+            const int32_t x = a[i], y = a[k];
+            a[i] = hb<BIT>(-COS(32), x, COS(32), y);
+            a[k] = hb<BIT>(COS(32), y, COS(32), x);
+        }
+    } else {
+        constexpr int NB = 1 << (J - 2), L = (M / 2) / NB;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int al = (16 / NB) * (1 + 4 * cbrev(b, J - 2));
+#pragma unroll
+            for (int t = L / 4; t < 3 * L / 4; t++) {
+                const int i = b * L + t, k = M - 1 - i;
+                const int32_t x = a[i], y = a[k];
+                if (t < L / 2) { a[i] = hb<BIT>(-COS(al), x, COS(64 - al), y);      a[k] = hb<BIT>(COS(al), y, COS(64 - al), x); }
+                else           { a[i] = hb<BIT>(-COS(64 - al), x, -COS(al), y);     a[k] = hb<BIT>(COS(64 - al), y, -COS(al), x); }
+            }
+        }
+    }
+}
+template <int BIT>
+__device__ __forceinline__ void rot_p(int32_t* p, int al)
+{
+    const int32_t x = p[0], y = p[1];
+    p[0] = hb<BIT>(COS(al), x, COS(64 - al), y);
+    p[1] = hb<BIT>(COS(64 - al), x, -COS(al), y);
+}
+template <int BIT>
+__device__ __forceinline__ void rot_q(int32_t* p, int al)
+{
+    const int32_t x = p[0], y = p[1];
+    p[0] = hb<BIT>(-COS(64 - al), x, COS(al), y);
+    p[1] = hb<BIT>(COS(al), x, COS(64 - al), y);
+}
+__device__ constexpr int8_t kVtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};  // vtx_tab (EbTransforms.h:88)
+__device__ constexpr int8_t kHtx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};  // htx_tab (:93)

@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
     L.svthip_fwd_txfm2d_batch_dev.restype = C.c_int32
     L.svthip_fwd_txfm2d_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                               C.c_void_p, C.c_void_p]
+    L.svthip_inv_txfm2d_add_batch_dev.restype = C.c_int32
+    L.svthip_inv_txfm2d_add_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                  C.c_uint32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -206,6 +209,14 @@ def _fwd_txfm2d_batch_dev(self, d_residual, d_desc, n_tu, tx_width, tx_height, b
 Context.fwd_txfm2d_batch_dev = _fwd_txfm2d_batch_dev
 
 
+def _inv_txfm2d_add_batch_dev(self, d_coeff, d_desc, n_tu, tx_width, tx_height, bit_depth, recon_16bit, d_recon, stream=None):
+    _check(lib().svthip_inv_txfm2d_add_batch_dev(self._h, d_coeff, d_desc, n_tu, tx_width, tx_height, bit_depth, int(recon_16bit),
+                                                 d_recon, stream))
+
+
+Context.inv_txfm2d_add_batch_dev = _inv_txfm2d_add_batch_dev
+
+
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
     """Descriptors for every SB of a picture the way MotionEstimateLcu derives them
     (Codec/EbMotionEstimation.c:6667-6738): window centred on `centers[sb] = (x, y)` (default 0,0),
@@ -264,6 +275,9 @@ assert QUANT_DESC_DTYPE.itemsize == 16
 
 TXFM_DESC_DTYPE = np.dtype([("in_offset", "<u4"), ("out_offset", "<u4"), ("in_stride", "<u2"), ("tx_type", "u1"), ("reserved", "u1")])
 assert TXFM_DESC_DTYPE.itemsize == 12
+ITXFM_DESC_DTYPE = np.dtype([("coeff_offset", "<u4"), ("recon_offset", "<u4"), ("recon_stride", "<u2"), ("tx_type", "u1"),
+                             ("reserved", "u1")])
+assert ITXFM_DESC_DTYPE.itemsize == 12
 
 # the 19 AV1 transform sizes (width, height), TxSize order (Codec/EbDefinitions.h)
 TX_SIZES_WH = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64),

@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 import svtav1_hip
-from tq_util import oracle_quant_batch, oracle_txfm_batch, random_quant_batch, random_txfm_batch
+from tq_util import (oracle_itxfm_batch, oracle_quant_batch, oracle_txfm_batch, random_itxfm_batch, random_quant_batch,
+                     random_txfm_batch)
 
 pytestmark = pytest.mark.gpu
 
@@ -63,3 +64,50 @@ def test_fwd_txfm2d_rejects_bad_arguments(hip_ctx):
         hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 8, 8, 12, buf.data_ptr())
     with pytest.raises(svtav1_hip.SvtHipError):
         hip_ctx.fwd_txfm2d_batch_dev(buf.data_ptr(), buf.data_ptr(), 1, 8, 8, 8, buf.data_ptr() + 4)  # misaligned output
+
+
+@pytest.mark.parametrize("size", svtav1_hip.TX_SIZES_WH)
+@pytest.mark.parametrize("mode", [(8, False), (8, True), (10, True)])
+def test_inv_txfm2d_add_batch_matches_oracle(hip_ctx, oracle, size, mode):
+    """Every size and defined type; 8-bit plane, widened 8-bit plane and 10-bit plane; inputs that hit every clamp."""
+    torch = pytest.importorskip("torch")
+    w, h = size
+    bit_depth, recon_16bit = mode
+    n_tu = 61 if w * h <= 1024 else 23
+    rng = np.random.default_rng(w * 1000 + h * 10 + bit_depth + int(recon_16bit))
+    b = random_itxfm_batch(rng, n_tu, w, h, bit_depth, recon_16bit)
+    ref = oracle_itxfm_batch(oracle, b)
+    d_coeff, d_desc, d_rec = _dev(b["coeff"]), _dev(b["desc"]), _dev(b["pred"])
+    torch.cuda.synchronize()
+    hip_ctx.inv_txfm2d_add_batch_dev(d_coeff.data_ptr(), d_desc.data_ptr(), n_tu, w, h, bit_depth, recon_16bit, d_rec.data_ptr())
+    hip_ctx.synchronize()
+    got = d_rec.cpu().numpy().view(b["pred"].dtype)
+    bad = np.flatnonzero(got != ref)
+    assert bad.size == 0, (size, mode, bad[:8], got[bad[:8]], ref[bad[:8]])
+
+
+def test_fwd_inv_round_trip_is_near_identity(hip_ctx):
+    """Size-independent property at frame scale: inverse(forward(residual)) added to a zero prediction returns the residual
+    within the transform pair's rounding error (|err| <= 2 for DCT_DCT 8-bit), for every square size."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(5)
+    pic_w, pic_h = 1920, 1024
+    res = rng.integers(0, 128, (pic_h, pic_w)).astype(np.int16)          # non-negative so the zero prediction does not clip it
+    d_res = _dev(res)
+    for n in (4, 8, 16, 32):
+        per_row = pic_w // n
+        n_tu = per_row * (pic_h // n)
+        idx = np.arange(n_tu)
+        off = (idx // per_row) * n * pic_w + (idx % per_row) * n
+        fd = np.zeros(n_tu, dtype=svtav1_hip.TXFM_DESC_DTYPE)
+        fd["in_offset"], fd["out_offset"], fd["in_stride"] = off, idx * n * n, pic_w
+        idd = np.zeros(n_tu, dtype=svtav1_hip.ITXFM_DESC_DTYPE)
+        idd["coeff_offset"], idd["recon_offset"], idd["recon_stride"] = idx * n * n, off, pic_w
+        d_fd, d_id = _dev(fd), _dev(idd)
+        d_coeff = torch.empty(n_tu * n * n, dtype=torch.int32, device="cuda:0")
+        d_rec = torch.zeros(pic_w * pic_h, dtype=torch.uint8, device="cuda:0")
+        hip_ctx.fwd_txfm2d_batch_dev(d_res.data_ptr(), d_fd.data_ptr(), n_tu, n, n, 8, d_coeff.data_ptr())
+        hip_ctx.inv_txfm2d_add_batch_dev(d_coeff.data_ptr(), d_id.data_ptr(), n_tu, n, n, 8, False, d_rec.data_ptr())
+        hip_ctx.synchronize()
+        err = np.abs(d_rec.cpu().numpy().reshape(pic_h, pic_w).astype(np.int32) - res.astype(np.int32))
+        assert err.max() <= 2, (n, int(err.max()))

@@ -135,3 +135,89 @@ def test_fwd_txfm2d_matches_reference(oracle, reftq, size):
             assert np.array_equal(oo, ro), (w, h, tx_type, trial, np.flatnonzero(oo != ro)[:8])
             n_checked += 1
     assert n_checked >= 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# inverse transforms + reconstruction
+# ---------------------------------------------------------------------------------------------------------------------
+INV_SIG5 = {(4, 4), (8, 8), (16, 16), (32, 32), (64, 64)}            # (input, output, stride, tx_type, bd)
+INV_SIG6 = {(4, 8), (8, 4), (4, 16), (16, 4)}                          # (..., tx_type, tx_size, bd)
+TX_SIZE_ENUM = {s: i for i, s in enumerate(FWD_SIZES)}                 # FWD_SIZES is in TxSize order
+
+
+def call_ref_inv(reftq, w, h, coeff, recon, stride, tx_type, bd):
+    f = getattr(reftq, f"av1_inv_txfm2d_add_{w}x{h}_c")
+    f.restype = None
+    if (w, h) in INV_SIG5:
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int32]
+        f(coeff.ctypes.data, recon.ctypes.data, stride, tx_type, bd)
+    elif (w, h) in INV_SIG6:
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int32]
+        f(coeff.ctypes.data, recon.ctypes.data, stride, tx_type, TX_SIZE_ENUM[(w, h)], bd)
+    else:
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int32, C.c_int32]
+        f(coeff.ctypes.data, recon.ctypes.data, stride, tx_type, TX_SIZE_ENUM[(w, h)], 1, bd)
+
+
+def inv_inputs(rng, n, kind, bd):
+    """Dequantised-coefficient-like inputs; kinds 3/4 are far out of range and exercise every clamp of the networks."""
+    if kind == 0:
+        return rng.laplace(0, 40 << (bd - 8), n).astype(np.int64)
+    if kind == 1:
+        x = np.zeros(n, np.int64); k = rng.integers(0, n, 4); x[k] = rng.integers(-(1 << (bd + 6)), 1 << (bd + 6), 4); return x
+    if kind == 2:
+        return rng.integers(-(1 << (bd + 7)), 1 << (bd + 7), n)
+    if kind == 3:
+        return rng.integers(-(1 << 20), 1 << 20, n)
+    if kind == 4:
+        return rng.choice([-(1 << (bd + 7)), (1 << (bd + 7)) - 1], n)
+    return np.zeros(n, np.int64)
+
+
+@pytest.mark.parametrize("size", FWD_SIZES)
+def test_inv_txfm2d_add_matches_reference(oracle, reftq, size):
+    w, h = size
+    orc = oracle.lib.orc_inv_txfm2d_add
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    oracle.lib.orc_fwd_txfm2d_valid.restype = C.c_int
+    rng = np.random.default_rng(w * 977 + h)
+    n_in = min(w, 32) * min(h, 32)
+    n_checked = 0
+    for tx_type in range(16):
+        if oracle.lib.orc_fwd_txfm2d_valid(w, h, tx_type) != 0:
+            continue
+        for trial in range(12):
+            bd = 10 if trial >= 6 else 8
+            stride = w + int(rng.integers(0, 9))
+            coeff = inv_inputs(rng, n_in, trial % 6, bd).astype(np.int32)
+            pred = rng.integers(0, 1 << bd, (h, stride)).astype(np.uint16)
+            r_rec = pred.copy(); o_rec = pred.copy()
+            call_ref_inv(reftq, w, h, coeff, r_rec, stride, tx_type, bd)
+            orc(coeff.ctypes.data, o_rec.ctypes.data, stride, w, h, tx_type, bd)
+            assert np.array_equal(o_rec, r_rec), (w, h, tx_type, trial, np.argwhere(o_rec != r_rec)[:6])
+            n_checked += 1
+    assert n_checked >= 12
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_inv_txfm2d_residual_matches_reference(oracle, reftq, n):
+    """Av1InverseTransformTwoD_NxN_c returns the residual before the pixel clip, so every clamp inside the networks shows."""
+    f = getattr(reftq, f"Av1InverseTransformTwoD_{n}x{n}_c")
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint8]
+    orc = oracle.lib.orc_inv_txfm2d
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int32]
+    oracle.lib.orc_fwd_txfm2d_valid.restype = C.c_int
+    rng = np.random.default_rng(n)
+    for tx_type in range(16):
+        if oracle.lib.orc_fwd_txfm2d_valid(n, n, tx_type) != 0:
+            continue
+        for trial in range(12):
+            bd = 10 if trial >= 6 else 8
+            coeff = inv_inputs(rng, n * n, trial % 6, bd).astype(np.int32)
+            ro = np.full(n * n, 7, np.int32); oo = np.full(n * n, 9, np.int32)
+            f(coeff.ctypes.data, n, ro.ctypes.data, n, tx_type, bd)
+            orc(coeff.ctypes.data, n, n, n, tx_type, bd, oo.ctypes.data, n)
+            assert np.array_equal(oo, ro), (n, tx_type, trial, np.flatnonzero(oo != ro)[:6])

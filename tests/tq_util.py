@@ -104,3 +104,45 @@ def oracle_txfm_batch(oracle, b):
         o = int(d["out_offset"])
         orc(res.ctypes.data + 2 * int(d["in_offset"]), int(d["in_stride"]), w, h, int(d["tx_type"]), out.ctypes.data + 4 * o)
     return out
+
+
+def random_itxfm_batch(rng, n_tu, w, h, bit_depth=8, recon_16bit=False, pic_w=512, pic_h=256):
+    """Non-overlapping TUs on a prediction plane; dequantised-coefficient-like inputs incl. out-of-range ones (clamps)."""
+    win, hin = min(w, 32), min(h, 32)
+    per_row = pic_w // w
+    assert n_tu <= per_row * (pic_h // h)
+    slots = rng.permutation(per_row * (pic_h // h))[:n_tu]
+    types = svtav1_hip.valid_tx_types(w, h)
+    desc = np.zeros(n_tu, dtype=svtav1_hip.ITXFM_DESC_DTYPE)
+    coeff = np.zeros(n_tu * win * hin, np.int32)
+    for i in range(n_tu):
+        sx, sy = int(slots[i]) % per_row, int(slots[i]) // per_row
+        desc[i] = (i * win * hin, sy * h * pic_w + sx * w, pic_w, types[int(rng.integers(0, len(types)))], 0)
+        kind = i % 6
+        n = win * hin
+        if kind == 0:
+            c = rng.laplace(0, 40 << (bit_depth - 8), n).astype(np.int64)
+        elif kind == 1:
+            c = np.zeros(n, np.int64); k = rng.integers(0, n, 4); c[k] = rng.integers(-(1 << (bit_depth + 6)), 1 << (bit_depth + 6), 4)
+        elif kind == 2:
+            c = rng.integers(-(1 << (bit_depth + 7)), 1 << (bit_depth + 7), n)
+        elif kind == 3:
+            c = rng.integers(-(1 << 20), 1 << 20, n)
+        elif kind == 4:
+            c = rng.choice([-(1 << (bit_depth + 7)), (1 << (bit_depth + 7)) - 1], n)
+        else:
+            c = np.zeros(n, np.int64)
+        coeff[i * n:(i + 1) * n] = c
+    pred = rng.integers(0, 1 << bit_depth, pic_w * pic_h).astype(np.uint16 if recon_16bit else np.uint8)
+    return {"coeff": coeff, "desc": desc, "pred": pred, "w": w, "h": h, "bit_depth": bit_depth, "recon_16bit": recon_16bit}
+
+
+def oracle_itxfm_batch(oracle, b):
+    orc = oracle.lib.orc_inv_txfm2d_add
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    rec = b["pred"].astype(np.uint16)         # av1_inv_txfm_add_c widens the 8-bit plane the same way (EbTransforms.c:8321-8340)
+    for d in b["desc"]:
+        orc(b["coeff"].ctypes.data + 4 * int(d["coeff_offset"]), rec.ctypes.data + 2 * int(d["recon_offset"]), int(d["recon_stride"]),
+            b["w"], b["h"], int(d["tx_type"]), b["bit_depth"])
+    return rec.astype(b["pred"].dtype)

@@ -16,47 +16,59 @@ import svtav1_hip  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--coeffs", type=int, default=1 << 23)
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--coeffs", type=int, default=1 << 26)
+    ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--sizes", type=str, default="")
     args = ap.parse_args()
     ctx = svtav1_hip.Context(0)
     tstream = torch.cuda.Stream()            # a real (non-null) stream: a null stream argument means "the context's stream"
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    pic_w, pic_h = 1920, 1088
+    pic_w = 8192
+    pic_h = max(64, (args.coeffs // pic_w) // 64 * 64)       # one residual / prediction plane holding every TU exactly once
     rng = np.random.default_rng(1)
-    res = torch.from_numpy(rng.integers(-255, 256, pic_w * pic_h).astype(np.int16)).to("cuda:0")
+    res = torch.from_numpy(rng.integers(-255, 256, pic_w * pic_h, dtype=np.int16)).to("cuda:0")
+    pred = torch.from_numpy(rng.integers(0, 256, pic_w * pic_h, dtype=np.uint8)).to("cuda:0")
     sizes = svtav1_hip.TX_SIZES_WH
     if args.sizes:
         sizes = [tuple(int(v) for v in s.split("x")) for s in args.sizes.split(",")]
-    for (w, h) in sizes:
-        n_tu = args.coeffs // (w * h)
-        # TUs tile the picture in raster order (wrapping), DCT_DCT, like an encode pass over a frame
-        per_row = pic_w // w
-        idx = np.arange(n_tu)
-        x0 = (idx % per_row) * w
-        y0 = ((idx // per_row) * h) % (pic_h - h + 1)
-        desc = np.zeros(n_tu, dtype=svtav1_hip.TXFM_DESC_DTYPE)
-        desc["in_offset"] = y0 * pic_w + x0
-        desc["out_offset"] = idx * (w * h)
-        desc["in_stride"] = pic_w
-        desc["tx_type"] = 0
-        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
-        d_out = torch.empty(n_tu * w * h, dtype=torch.int32, device="cuda:0")
-        for _ in range(3):
-            ctx.fwd_txfm2d_batch_dev(res.data_ptr(), d_desc.data_ptr(), n_tu, w, h, 8, d_out.data_ptr(), stream)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
-            ctx.fwd_txfm2d_batch_dev(res.data_ptr(), d_desc.data_ptr(), n_tu, w, h, 8, d_out.data_ptr(), stream)
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.iters
+        return e0.elapsed_time(e1) / args.iters
+
+    for (w, h) in sizes:
+        per_row = pic_w // w
+        n_tu = per_row * (pic_h // h)
+        idx = np.arange(n_tu)
+        off = (idx // per_row) * h * pic_w + (idx % per_row) * w
+        desc = np.zeros(n_tu, dtype=svtav1_hip.TXFM_DESC_DTYPE)
+        desc["in_offset"], desc["out_offset"], desc["in_stride"] = off, idx * (w * h), pic_w
+        win, hin = min(w, 32), min(h, 32)
+        idesc = np.zeros(n_tu, dtype=svtav1_hip.ITXFM_DESC_DTYPE)
+        idesc["coeff_offset"], idesc["recon_offset"], idesc["recon_stride"] = idx * (win * hin), off, pic_w
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        d_idesc = torch.from_numpy(idesc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        d_out = torch.empty(n_tu * w * h, dtype=torch.int32, device="cuda:0")
         nc = n_tu * w * h
-        print(f"fwd_txfm {w:2d}x{h:2d}  n_tu {n_tu:7d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gcoeff/s  {nc * 6 / ms / 1e6:8.1f} GB/s algorithmic",
+        ms = timed(lambda: ctx.fwd_txfm2d_batch_dev(res.data_ptr(), d_desc.data_ptr(), n_tu, w, h, 8, d_out.data_ptr(), stream))
+        print(f"fwd_txfm {w:2d}x{h:2d}  n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gcoeff/s  {nc * 6 / ms / 1e6:8.1f} GB/s algorithmic",
               flush=True)
+        d_out >>= 3                                           # keep the inverse input in a plausible dequantised range
+        ms = timed(lambda: ctx.inv_txfm2d_add_batch_dev(d_out.data_ptr(), d_idesc.data_ptr(), n_tu, w, h, 8, False, pred.data_ptr(),
+                                                        stream))
+        ib = n_tu * (win * hin * 4 + 2 * w * h)               # coefficients in + prediction read + reconstruction written
+        print(f"inv_txfm {w:2d}x{h:2d}  n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gpix/s    {ib / ms / 1e6:8.1f} GB/s algorithmic",
+              flush=True)
+        del d_out
 
 
 if __name__ == "__main__":
