@@ -292,6 +292,46 @@ int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx *ctx, const int32_t *d_coeff,
                                         uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, uint32_t recon_16bit,
                                         void *d_recon, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused per-TU encode chain (8-bit planes).  One call does, for n_tu units of ONE size, what Av1EncodeLoop
+ * (Source/Lib/Codec/EbCodingLoop.c:552-760) does per TU with ResidualKernel (Codec/EbPictureOperators.c:257-285),
+ * Av1EstimateTransform (Codec/EbTransforms.c:4410-4728), Av1QuantizeInvQuantize (Codec/EbFullLoop.c:877-941),
+ * FullDistortionKernel32Bits (Codec/EbPictureOperators.c:374-404) and Av1InvTransformRecon8bit
+ * (Codec/EbTransforms.c:8374-8399), without the intermediate buffers going through memory.
+ *
+ * d_src / d_pred / d_recon : uint8 planes; TU i reads source and prediction at src_offset / pred_offset (+ r * stride) and
+ *                writes clip(pred + inverse(dequantised)) at recon_offset.  d_recon may be d_pred (same offsets and stride):
+ *                in-place reconstruction as the reference does.  TUs of one call must not overlap in d_recon.
+ * coefficient pools (int32, 16-byte aligned; TU i at coeff_offset, multiple of 4, min(W,32) x min(H,32) values with row
+ *                stride min(W,32) -- Av1EstimateTransform's packed layout):
+ *                d_coeff (transform output, may be NULL), d_qcoeff (required), d_dqcoeff (may be NULL).
+ * d_qparams / d_iscan : as svthip_quantize_b_batch_dev; log_scale is av1_get_tx_scale of the size.
+ * d_eob[i]     : uint16 end of block (= y_count_non_zero_coeffs of the reference).
+ * d_three_quad_energy[i] (may be NULL) : energy of the coefficients a 64-point dimension drops (HandleTransform64x64_c etc.,
+ *                Codec/EbTransforms.c:3894-3926), 0 for the other sizes.
+ * d_distortion (may be NULL) : uint64 [n_tu][2] = {sum (coeff - dqcoeff)^2, sum coeff^2} over the packed block
+ *                (DIST_CALC_RESIDUAL, DIST_CALC_PREDICTION; the caller adds three_quad_energy and shifts as in
+ *                Codec/EbFullLoop.c:1040-1045). */
+typedef struct svthip_tu_desc {
+    uint32_t src_offset;
+    uint32_t pred_offset;
+    uint32_t recon_offset;
+    uint32_t coeff_offset;
+    uint32_t iscan_offset;
+    uint16_t src_stride;
+    uint16_t pred_stride;
+    uint16_t recon_stride;
+    uint16_t qparam_index;
+    uint8_t tx_type;
+    uint8_t reserved[3];
+} svthip_tu_desc;
+
+int32_t svthip_encode_tu_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, const uint8_t *d_pred, uint8_t *d_recon,
+                                   const svthip_tu_desc *d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                   const int16_t *d_qparams, const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                                   int32_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_three_quad_energy, uint64_t *d_distortion,
+                                   void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

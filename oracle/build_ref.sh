@@ -108,7 +108,7 @@ echo "built $OUT/libsvtref_me.so (unresolved by design: $(nm -D "$OUT/libsvtref_
 # transform/quant kernels): Av1TransformTwoD_NxN_c, av1_fwd_txfm2d_WxH_c, Av1InverseTransformTwoD_NxN_c,
 # av1_inv_txfm2d_add_WxH_c (Codec/EbTransforms.c) and aom_quantize_b*_c_II / aom_highbd_quantize_b*_c
 # (Codec/EbFullLoop.c).  Same objects, same no-stand-in rule; lazy binding for anything NASM-only.
-printf '{ global: Av1TransformTwoD_*_c; av1_fwd_txfm2d_*_c; Av1InverseTransformTwoD_*_c; av1_inv_txfm2d_add_*_c; aom_quantize_b*_c_II; aom_highbd_quantize_b*_c; av1_cospi_arr_data; av1_sinpi_arr_data; local: *; };\n' > "$OUT/obj/tq.map"
+printf '{ global: Av1TransformTwoD_*_c; av1_fwd_txfm2d_*_c; Av1InverseTransformTwoD_*_c; av1_inv_txfm2d_add_*_c; aom_quantize_b*_c_II; aom_highbd_quantize_b*_c; av1_cospi_arr_data; av1_sinpi_arr_data; HandleTransform*_c; EnergyComputation; FullDistortionKernel32Bits; ResidualKernel_c; local: *; };\n' > "$OUT/obj/tq.map"
 gcc -shared -o "$OUT/libsvtref_tq.so" "$OUT"/obj_all/*.o \
     -Wl,--gc-sections -Wl,--version-script="$OUT/obj/tq.map" -lm -lpthread
 echo "built $OUT/libsvtref_tq.so (unresolved: $(nm -D "$OUT/libsvtref_tq.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"

@@ -444,3 +444,58 @@ void orc_inv_txfm2d_add(const int32_t *input, uint16_t *output, int32_t stride, 
             output[r * stride + c] = (uint16_t)(p < 0 ? 0 : (p > pix_max ? pix_max : p));
         }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Glue of the encode pass (row a20) and the per-TU chain of Av1EncodeLoop (Source/Lib/Codec/EbCodingLoop.c:552-760):
+ * ResidualKernel -> Av1EstimateTransform -> Av1QuantizeInvQuantize -> Av1InvTransformRecon8bit.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* Av1EstimateTransform's handling of 64-point dimensions (EbTransforms.c:4440-4470, :4640-4660; HandleTransform*_c
+ * :3894-3926, :4072-4222): energy of the coefficients outside the top-left min(w,32) x min(h,32), which are dropped, and
+ * re-packing of the kept part to row stride min(w,32).  full: w x h transform output; packed: min(w,32) x min(h,32). */
+uint64_t orc_pack_transform(const int32_t *full, int w, int h, int32_t *packed)
+{
+    const int win = w > 32 ? 32 : w, hin = h > 32 ? 32 : h;
+    uint64_t energy = 0;
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) {
+            const int64_t v = full[r * w + c];
+            if (r < hin && c < win) packed[r * win + c] = (int32_t)v;
+            else energy += (uint64_t)(v * v);
+        }
+    return energy;
+}
+int orc_tx_log_scale(int w, int h) { return (w * h > 256) + (w * h > 1024); } /* av1_get_tx_scale, EbTransforms.h:312-316 */
+
+/* FullDistortionKernel32Bits (EbPictureOperators.c:374-404) on a dense n-coefficient block */
+void orc_full_distortion(const int32_t *coeff, const int32_t *recon_coeff, int n, uint64_t dist[2])
+{
+    uint64_t res = 0, pred = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t d = (int64_t)coeff[i] - recon_coeff[i], c = coeff[i];
+        res += (uint64_t)(d * d);
+        pred += (uint64_t)(c * c);
+    }
+    dist[0] = res;
+    dist[1] = pred;
+}
+
+void orc_encode_tu(const uint8_t *src, int32_t src_stride, const uint8_t *pred, int32_t pred_stride, uint8_t *recon,
+                   int32_t recon_stride, int w, int h, int tx_type, const int16_t *qp, const int16_t *scan, int32_t *coeff,
+                   int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, uint64_t *three_quad_energy, uint64_t dist[2])
+{
+    static __thread int16_t residual[64 * 64];
+    static __thread int32_t full[64 * 64];
+    static __thread uint16_t rec16[64 * 64];
+    const int win = w > 32 ? 32 : w, hin = h > 32 ? 32 : h;
+    for (int r = 0; r < h; r++) /* ResidualKernel (EbPictureOperators.c:257-285) */
+        for (int c = 0; c < w; c++) residual[r * w + c] = (int16_t)((int)src[r * src_stride + c] - (int)pred[r * pred_stride + c]);
+    orc_fwd_txfm2d(residual, w, w, h, tx_type, full);
+    *three_quad_energy = orc_pack_transform(full, w, h, coeff);
+    orc_quantize_b(coeff, win * hin, qp, scan, orc_tx_log_scale(w, h), 0, qcoeff, dqcoeff, eob);
+    orc_full_distortion(coeff, dqcoeff, win * hin, dist);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) rec16[r * w + c] = pred[r * pred_stride + c];
+    if (*eob) orc_inv_txfm2d_add(dqcoeff, rec16, w, w, h, tx_type, 8); /* only when the TU has coefficients (:717-727) */
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) recon[r * recon_stride + c] = (uint8_t)rec16[r * w + c];
+}

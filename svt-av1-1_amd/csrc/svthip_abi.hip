@@ -247,6 +247,29 @@ int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff,
     return SVTHIP_OK;
 }
 
+int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const uint8_t* d_pred, uint8_t* d_recon,
+                                   const svthip_tu_desc* d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                   const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
+                                   int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion,
+                                   void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
+    if (n_tu == 0) return SVTHIP_OK;
+    if (!d_src || !d_pred || !d_recon || !d_desc || !d_qparams || !d_iscan || !d_qcoeff || !d_eob)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if ((reinterpret_cast<uintptr_t>(d_coeff) | reinterpret_cast<uintptr_t>(d_qcoeff) | reinterpret_cast<uintptr_t>(d_dqcoeff)) & 15u)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "coefficient pools must be 16-byte aligned%s", "");
+    if (reinterpret_cast<uintptr_t>(d_iscan) & 7u) return fail(SVTHIP_ERR_BAD_PARAMETER, "iscan pool must be 8-byte aligned%s", "");
+    if ((reinterpret_cast<uintptr_t>(d_three_quad_energy) | reinterpret_cast<uintptr_t>(d_distortion)) & 7u)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "energy / distortion outputs must be 8-byte aligned%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qparams, d_iscan, d_coeff,
+                                     d_qcoeff, d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, s));
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                         const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
                                         const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,

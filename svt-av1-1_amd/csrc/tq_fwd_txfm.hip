@@ -29,173 +29,7 @@ namespace {
 
 #include "tq_txfm_common.h"
 
-// ---- DCT: recursive even/odd split; the odd half is rotation layers interleaved with mirrored add/sub layers ----------
-template <int M, int SPAN>
-__device__ __forceinline__ void odd_bfly(int32_t* a)
-{
-#pragma unroll
-    for (int base = 0; base < M; base += SPAN)
-#pragma unroll
-        for (int t = 0; t < SPAN / 2; t++) {
-            const int i = base + t, j = base + SPAN - 1 - t;
-            const int32_t lo = a[i], hi = a[j];
-            if (((base / SPAN) & 1) == 0) { a[i] = lo + hi; a[j] = lo - hi; }
-            else                          { a[i] = hi - lo; a[j] = hi + lo; }
-        }
-}
-template <int M, int J, int BIT>
-__device__ __forceinline__ void odd_layers(int32_t* a)
-{
-    if constexpr (J < clog2(M)) {
-        odd_rot<M, J, BIT>(a);
-        odd_bfly<M, (M >> J)>(a);
-        odd_layers<M, J + 1, BIT>(a);
-    }
-}
-template <int M, int BIT>
-__device__ __forceinline__ void dct_odd(int32_t* a)
-{
-    constexpr int m = clog2(M);
-    odd_layers<M, 1, BIT>(a);
-#pragma unroll
-    for (int k = 0; k < M / 2; k++) {
-        const int al = (32 / M) * (1 + 4 * cbrev(k, m - 1)), q = M - 1 - k;
-        const int32_t x = a[k], y = a[q];
-        a[k] = hb<BIT>(COS(64 - al), x, COS(al), y);
-        a[q] = hb<BIT>(COS(64 - al), y, -COS(al), x);
-    }
-}
-template <int N, int BIT, int OS>
-__device__ __forceinline__ void fdct(const int32_t* x, int32_t* out)
-{
-    if constexpr (N == 2) {
-        out[0] = hb<BIT>(COS(32), x[0], COS(32), x[1]);
-        out[OS] = hb<BIT>(-COS(32), x[1], COS(32), x[0]);
-    } else {
-        constexpr int M = N / 2, m = clog2(M);
-        int32_t s[M], a[M];
-#pragma unroll
-        for (int i = 0; i < M; i++) {
-            s[i] = x[i] + x[N - 1 - i];
-            a[i] = x[M - 1 - i] - x[M + i];
-        }
-        fdct<M, BIT, 2 * OS>(s, out);
-        dct_odd<M, BIT>(a);
-#pragma unroll
-        for (int k = 0; k < M; k++) out[(1 + 2 * cbrev(k, m)) * OS] = a[k];
-    }
-}
-
-// ---- ADST ---------------------------------------------------------------------------------------------------------------
-template <int N, int SPAN>
-__device__ __forceinline__ void span_bfly(int32_t* f)
-{
-#pragma unroll
-    for (int base = 0; base < N; base += 2 * SPAN)
-#pragma unroll
-        for (int t = 0; t < SPAN; t++) {
-            const int32_t x = f[base + t], y = f[base + SPAN + t];
-            f[base + t] = x + y;
-            f[base + SPAN + t] = x - y;
-        }
-}
-template <int BIT>
-__device__ __forceinline__ void fadst4(const int32_t* x, int32_t* out)
-{
-    // int32 wrap-around arithmetic as in the reference (:2764-2854); the all-zero shortcut yields the same zeros
-    const uint32_t s1 = kSinpi[BIT - 10][1], s2 = kSinpi[BIT - 10][2], s3 = kSinpi[BIT - 10][3], s4 = kSinpi[BIT - 10][4];
-    const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-    const uint32_t p = s1 * x0 + s2 * x1 + s4 * x3;
-    const uint32_t q = s4 * x0 - s1 * x1 + s2 * x3;
-    const uint32_t r = s3 * x2;
-    out[0] = rs<BIT>((int32_t)(p + r));
-    out[1] = rs<BIT>((int32_t)(s3 * (x0 + x1 - x3)));
-    out[2] = rs<BIT>((int32_t)(q - r));
-    out[3] = rs<BIT>((int32_t)(q - p + r));
-}
-template <int N, int BIT>
-__device__ __forceinline__ void fadst(const int32_t* x, int32_t* out)
-{
-    if constexpr (N == 4) {
-        fadst4<BIT>(x, out);
-    } else {
-        constexpr int8_t idx8[8] = {0, 7, 3, 4, 1, 6, 2, 5};
-        constexpr int8_t idx16[16] = {0, 15, 7, 8, 3, 12, 4, 11, 1, 14, 6, 9, 2, 13, 5, 10};
-        constexpr uint32_t neg8 = 0x96, neg16 = 0x6996;  // bit i set: input i of the permuted vector is negated
-        int32_t f[N];
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            const int32_t v = x[N == 8 ? idx8[i & 7] : idx16[i & 15]];
-            f[i] = (((N == 8 ? neg8 : neg16) >> i) & 1) ? -v : v;
-        }
-#pragma unroll
-        for (int g = 0; g < N; g += 4) rot_p<BIT>(f + g + 2, 32);
-        span_bfly<N, 2>(f);
-#pragma unroll
-        for (int g = 0; g < N; g += 8) {
-            rot_p<BIT>(f + g + 4, 16);
-            rot_q<BIT>(f + g + 6, 16);
-        }
-        span_bfly<N, 4>(f);
-        if constexpr (N == 16) {
-            rot_p<BIT>(f + 8, 8);
-            rot_p<BIT>(f + 10, 40);
-            rot_q<BIT>(f + 12, 8);
-            rot_q<BIT>(f + 14, 40);
-            span_bfly<N, 8>(f);
-        }
-#pragma unroll
-        for (int k = 0; k < N / 2; k++) rot_p<BIT>(f + 2 * k, N == 8 ? 4 + 16 * k : 2 + 8 * k);
-#pragma unroll
-        for (int i = 0; i < N / 2; i++) {
-            out[2 * i] = f[2 * i + 1];
-            out[2 * i + 1] = f[N - 2 - 2 * i];
-        }
-    }
-}
-template <int N>
-__device__ __forceinline__ void fidentity(const int32_t* x, int32_t* out)
-{
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        if constexpr (N == 4) out[i] = rs<12>((int64_t)x[i] * 5793);
-        else if constexpr (N == 8) out[i] = x[i] * 2;
-        else if constexpr (N == 16) out[i] = rs<12>((int64_t)x[i] * (2 * 5793));
-        else out[i] = x[i] * 4;
-    }
-}
-
-// kind: TX_TYPE_1D (0 DCT, 1 ADST, 2 FLIPADST, 3 IDTX)
-template <int N, int BIT>
-__device__ __forceinline__ void txfm1d(int kind, const int32_t* x, int32_t* out)
-{
-    if constexpr (N == 64) {
-        fdct<N, BIT, 1>(x, out);
-    } else if constexpr (N == 32) {
-        if (kind == 3) fidentity<N>(x, out);
-        else fdct<N, BIT, 1>(x, out);
-    } else {
-        if (kind == 0) fdct<N, BIT, 1>(x, out);
-        else if (kind == 3) fidentity<N>(x, out);
-        else fadst<N, BIT>(x, out);
-    }
-}
-template <int SH>
-__device__ __forceinline__ int32_t shift_val(int32_t v)  // av1_round_shift_array_c with bit = -SH
-{
-    if constexpr (SH == 0) return v;
-    else if constexpr (SH > 0) return v * (1 << SH);
-    else return rs<-SH>((int64_t)v);
-}
-
-
-constexpr int kCosCol[5][5] = {{13, 13, 13, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 13, 12, 13}, {0, 13, 13, 12, 13}, {0, 0, 13, 12, 13}};
-constexpr int kCosRow[5][5] = {{13, 13, 12, 0, 0}, {13, 13, 13, 12, 0}, {13, 13, 12, 13, 12}, {0, 12, 13, 12, 11}, {0, 0, 12, 11, 10}};
-constexpr int kShift[5][5][3] = {{{2, 0, 0}, {2, -1, 0}, {2, -1, 0}, {0, 0, 0}, {0, 0, 0}},
-                                 {{2, -1, 0}, {2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {0, 0, 0}},
-                                 {{2, -1, 0}, {2, -2, 0}, {2, -2, 0}, {2, -4, 0}, {0, -2, 0}},
-                                 {{0, 0, 0}, {2, -2, 0}, {2, -4, 0}, {2, -4, 0}, {0, -2, -2}},
-                                 {{0, 0, 0}, {0, 0, 0}, {2, -4, 0}, {2, -4, -2}, {0, -2, -2}}};
+#include "tq_fwd_networks.h"
 
 template <int WL, int HL>
 __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restrict__ residual, const svthip_txfm_desc* __restrict__ desc,

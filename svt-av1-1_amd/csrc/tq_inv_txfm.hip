@@ -26,170 +26,7 @@ namespace {
 
 #include "tq_txfm_common.h"
 
-struct Clamp {
-    int32_t lo, hi;
-    __device__ __forceinline__ int32_t operator()(int32_t v) const { return min(max(v, lo), hi); }
-};
-
-template <int M, int SPAN>
-__device__ __forceinline__ void odd_bfly_c(int32_t* a, const Clamp cl)
-{
-#pragma unroll
-    for (int base = 0; base < M; base += SPAN)
-#pragma unroll
-        for (int t = 0; t < SPAN / 2; t++) {
-            const int i = base + t, j = base + SPAN - 1 - t;
-            const int32_t lo = a[i], hi = a[j];
-            if (((base / SPAN) & 1) == 0) { a[i] = cl(lo + hi); a[j] = cl(lo - hi); }
-            else                          { a[i] = cl(hi - lo); a[j] = cl(hi + lo); }
-        }
-}
-template <int M, int J, int BIT>
-__device__ __forceinline__ void odd_layers_inv(int32_t* a, const Clamp cl)
-{
-    if constexpr (J >= 1) {
-        odd_bfly_c<M, (M >> J)>(a, cl);
-        odd_rot<M, J, BIT>(a);
-        odd_layers_inv<M, J - 1, BIT>(a, cl);
-    }
-}
-// x[i * XS], i < N: coefficients in natural order; inputs with index >= NZ are known to be zero
-template <int N, int BIT, int XS, int NZ>
-__device__ __forceinline__ void idct(const int32_t* x, int32_t* out, const Clamp cl)
-{
-    if constexpr (N == 2) {
-        const int32_t x1 = (XS < NZ) ? x[XS] : 0;
-        out[0] = hb<BIT>(COS(32), x[0], COS(32), x1);
-        out[1] = hb<BIT>(COS(32), x[0], -COS(32), x1);
-    } else {
-        constexpr int M = N / 2, m = clog2(M);
-        int32_t e[M], d[M];
-        idct<M, BIT, 2 * XS, NZ>(x, e, cl);
-#pragma unroll
-        for (int k = 0; k < M; k++) {
-            const int src = (1 + 2 * cbrev(k, m)) * XS;
-            d[k] = src < NZ ? x[src] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < M / 2; k++) {
-            const int al = (32 / M) * (1 + 4 * cbrev(k, m - 1)), q = M - 1 - k;
-            const int32_t u = d[k], v = d[q];
-            d[k] = hb<BIT>(COS(64 - al), u, -COS(al), v);
-            d[q] = hb<BIT>(COS(al), u, COS(64 - al), v);
-        }
-        odd_layers_inv<M, m - 1, BIT>(d, cl);
-        // outputs are written in index order: branches of itxfm1d that end with stores to different elements make the
-        // compiler merge them into one store through a selected address, which forces the array into scratch
-#pragma unroll
-        for (int i = 0; i < M; i++) out[i] = cl(e[i] + d[M - 1 - i]);
-#pragma unroll
-        for (int i = M; i < N; i++) out[i] = cl(e[N - 1 - i] - d[i - M]);
-    }
-}
-
-template <int N, int SPAN>
-__device__ __forceinline__ void span_bfly_c(int32_t* f, const Clamp cl)
-{
-#pragma unroll
-    for (int base = 0; base < N; base += 2 * SPAN)
-#pragma unroll
-        for (int t = 0; t < SPAN; t++) {
-            const int32_t x = f[base + t], y = f[base + SPAN + t];
-            f[base + t] = cl(x + y);
-            f[base + SPAN + t] = cl(x - y);
-        }
-}
-template <int BIT>
-__device__ __forceinline__ void iadst4(const int32_t* x, int32_t* out)
-{
-    // int32 wrap-around arithmetic as in the reference (:5538-5600)
-    const uint32_t s1 = kSinpi[BIT - 10][1], s2 = kSinpi[BIT - 10][2], s3 = kSinpi[BIT - 10][3], s4 = kSinpi[BIT - 10][4];
-    const uint32_t x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
-    const uint32_t A = s1 * x0 + s4 * x2 + s2 * x3;
-    const uint32_t B = s2 * x0 - s1 * x2 - s4 * x3;
-    const uint32_t Cc = s3 * x1;
-    out[0] = rs<BIT>((int32_t)(A + Cc));
-    out[1] = rs<BIT>((int32_t)(B + Cc));
-    out[2] = rs<BIT>((int32_t)(s3 * (x0 - x2 + x3)));
-    out[3] = rs<BIT>((int32_t)(A + B - Cc));
-}
-constexpr int iadst_out_index(int n, int i)  // output i takes network position ... (sign alternates, odd outputs negated)
-{
-    constexpr int o8[8] = {0, 4, 6, 2, 3, 7, 5, 1};
-    constexpr int o16[16] = {0, 8, 12, 4, 6, 14, 10, 2, 3, 11, 15, 7, 5, 13, 9, 1};
-    return n == 8 ? o8[i & 7] : o16[i & 15];
-}
-template <int N, int I>
-__device__ __forceinline__ void iadst_store(const int32_t* f, int32_t* out)
-{
-    if constexpr (I < N) {
-        constexpr int src = iadst_out_index(N, I);
-        out[I] = (I & 1) ? -f[src] : f[src];
-        iadst_store<N, I + 1>(f, out);
-    }
-}
-template <int N, int BIT>
-__device__ __forceinline__ void iadst(const int32_t* x, int32_t* out, const Clamp cl)
-{
-    if constexpr (N == 4) {
-        iadst4<BIT>(x, out);
-    } else {
-        int32_t f[N];
-#pragma unroll
-        for (int i = 0; i < N / 2; i++) {
-            f[2 * i] = x[N - 1 - 2 * i];
-            f[2 * i + 1] = x[2 * i];
-        }
-#pragma unroll
-        for (int k = 0; k < N / 2; k++) rot_p<BIT>(f + 2 * k, N == 8 ? 4 + 16 * k : 2 + 8 * k);
-        span_bfly_c<N, N / 2>(f, cl);
-        if constexpr (N == 16) {
-            rot_p<BIT>(f + 8, 8);
-            rot_p<BIT>(f + 10, 40);
-            rot_q<BIT>(f + 12, 8);
-            rot_q<BIT>(f + 14, 40);
-            span_bfly_c<N, 4>(f, cl);
-        }
-#pragma unroll
-        for (int g = 0; g < N; g += 8) {
-            rot_p<BIT>(f + g + 4, 16);
-            rot_q<BIT>(f + g + 6, 16);
-        }
-        span_bfly_c<N, 2>(f, cl);
-#pragma unroll
-        for (int g = 0; g < N; g += 4) rot_p<BIT>(f + g + 2, 32);
-        iadst_store<N, 0>(f, out);
-    }
-}
-template <int N>
-__device__ __forceinline__ void iidentity(const int32_t* x, int32_t* out)
-{
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        if constexpr (N == 4) out[i] = rs<12>((int64_t)x[i] * 5793);
-        else if constexpr (N == 8) out[i] = x[i] * 2;
-        else if constexpr (N == 16) out[i] = rs<12>((int64_t)x[i] * (2 * 5793));
-        else out[i] = x[i] * 4;
-    }
-}
-template <int N, int NZ>
-__device__ __forceinline__ void itxfm1d(int kind, const int32_t* x, int32_t* out, const Clamp cl)
-{
-    constexpr int BIT = 12;  // INV_COS_BIT for every size (EbTransforms.h:241-254)
-    if constexpr (N == 64) {
-        idct<N, BIT, 1, NZ>(x, out, cl);
-    } else if constexpr (N == 32) {
-        if (kind == 3) iidentity<N>(x, out);
-        else idct<N, BIT, 1, NZ>(x, out, cl);
-    } else {
-        if (kind == 0) idct<N, BIT, 1, NZ>(x, out, cl);
-        else if (kind == 3) iidentity<N>(x, out);
-        else iadst<N, BIT>(x, out, cl);
-    }
-}
-
-// inv_shift_WxH[0] (EbTransforms.h:255-273) as a right-shift amount, [log2 w - 2][log2 h - 2]; shift[1] is 4 for every size
-constexpr int kInvShift0[5][5] = {{0, 0, 1, 0, 0}, {0, 1, 1, 2, 0}, {1, 1, 2, 1, 2}, {0, 2, 1, 2, 1}, {0, 0, 2, 1, 2}};
+#include "tq_inv_networks.h"
 
 template <int WL, int HL, typename PIX>
 __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __restrict__ coeff, const svthip_itxfm_desc* __restrict__ desc,

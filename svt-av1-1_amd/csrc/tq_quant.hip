@@ -19,25 +19,7 @@
 namespace svthip {
 
 namespace {
-__device__ __forceinline__ int32_t rpot(int32_t v, int n) { return n == 0 ? v : ((v + (1 << (n - 1))) >> n); }
-
-__device__ __forceinline__ void quant_one(int32_t c, int ac, const int32_t* zb, const int32_t* rnd, const int16_t* qp, int log_scale,
-                                          int highbd, int32_t& q, int32_t& dq)
-{
-    const int32_t sign = c >> 31;
-    const int32_t abs_c = (c ^ sign) - sign;
-    q = 0;
-    dq = 0;
-    if (abs_c >= zb[ac]) {
-        long long tmp = (long long)abs_c + rnd[ac];
-        if (!highbd) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX); tmp >= 0 here
-        tmp *= 32;
-        const int32_t level = (int32_t)(((((tmp * qp[4 + ac]) >> 16) + tmp) * qp[6 + ac]) >> (16 - log_scale + 5));
-        q = (level ^ sign) - sign;
-        const int32_t abs_dq = (int32_t)((uint32_t)level * (uint32_t)(int32_t)qp[8 + ac]) >> log_scale;
-        dq = (abs_dq ^ sign) - sign;
-    }
-}
+#include "tq_quant_common.h"
 }  // namespace
 
 __global__ void __launch_bounds__(256) quantize_b_batch_kernel(const int32_t* __restrict__ coeff,

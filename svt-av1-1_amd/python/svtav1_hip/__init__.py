@@ -87,6 +87,9 @@ def lib() -> C.CDLL:
     L.svthip_inv_txfm2d_add_batch_dev.restype = C.c_int32
     L.svthip_inv_txfm2d_add_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                   C.c_uint32, C.c_void_p, C.c_void_p]
+    L.svthip_encode_tu_batch_dev.restype = C.c_int32
+    L.svthip_encode_tu_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                             C.c_uint32] + [C.c_void_p] * 9
     _lib = L
     return L
 
@@ -217,6 +220,15 @@ def _inv_txfm2d_add_batch_dev(self, d_coeff, d_desc, n_tu, tx_width, tx_height, 
 Context.inv_txfm2d_add_batch_dev = _inv_txfm2d_add_batch_dev
 
 
+def _encode_tu_batch_dev(self, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan, d_coeff, d_qcoeff,
+                         d_dqcoeff, d_eob, d_energy=None, d_dist=None, stream=None):
+    _check(lib().svthip_encode_tu_batch_dev(self._h, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan,
+                                            d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_energy, d_dist, stream))
+
+
+Context.encode_tu_batch_dev = _encode_tu_batch_dev
+
+
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
     """Descriptors for every SB of a picture the way MotionEstimateLcu derives them
     (Codec/EbMotionEstimation.c:6667-6738): window centred on `centers[sb] = (x, y)` (default 0,0),
@@ -278,6 +290,10 @@ assert TXFM_DESC_DTYPE.itemsize == 12
 ITXFM_DESC_DTYPE = np.dtype([("coeff_offset", "<u4"), ("recon_offset", "<u4"), ("recon_stride", "<u2"), ("tx_type", "u1"),
                              ("reserved", "u1")])
 assert ITXFM_DESC_DTYPE.itemsize == 12
+TU_DESC_DTYPE = np.dtype([("src_offset", "<u4"), ("pred_offset", "<u4"), ("recon_offset", "<u4"), ("coeff_offset", "<u4"),
+                          ("iscan_offset", "<u4"), ("src_stride", "<u2"), ("pred_stride", "<u2"), ("recon_stride", "<u2"),
+                          ("qparam_index", "<u2"), ("tx_type", "u1"), ("reserved", "u1", (3,))])
+assert TU_DESC_DTYPE.itemsize == 32
 
 # the 19 AV1 transform sizes (width, height), TxSize order (Codec/EbDefinitions.h)
 TX_SIZES_WH = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (8, 16), (16, 8), (16, 32), (32, 16), (32, 64),

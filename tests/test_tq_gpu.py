@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import svtav1_hip
-from tq_util import (oracle_itxfm_batch, oracle_quant_batch, oracle_txfm_batch, random_itxfm_batch, random_quant_batch,
+from tq_util import (oracle_encode_batch, random_encode_batch, oracle_itxfm_batch, oracle_quant_batch, oracle_txfm_batch, random_itxfm_batch, random_quant_batch,
                      random_txfm_batch)
 
 pytestmark = pytest.mark.gpu
@@ -111,3 +111,60 @@ def test_fwd_inv_round_trip_is_near_identity(hip_ctx):
         hip_ctx.synchronize()
         err = np.abs(d_rec.cpu().numpy().reshape(pic_h, pic_w).astype(np.int32) - res.astype(np.int32))
         assert err.max() <= 2, (n, int(err.max()))
+
+
+@pytest.mark.parametrize("size", svtav1_hip.TX_SIZES_WH)
+@pytest.mark.parametrize("in_place", [False, True])
+def test_encode_tu_batch_matches_oracle(hip_ctx, oracle, size, in_place):
+    """Fused residual -> transform -> quantise -> dequantise -> inverse -> reconstruct vs the chain of pinned oracle stages."""
+    torch = pytest.importorskip("torch")
+    w, h = size
+    n_tu = 53 if w * h <= 1024 else 21
+    rng = np.random.default_rng(w * 100 + h + int(in_place))
+    b = random_encode_batch(rng, n_tu, w, h)
+    ref = oracle_encode_batch(oracle, b)
+    n = b["n"]
+    d_src, d_pred, d_desc, d_qp, d_iscan = _dev(b["src"]), _dev(b["pred"]), _dev(b["desc"]), _dev(b["qparams"]), _dev(b["iscan"])
+    d_recon = d_pred if in_place else torch.full_like(d_pred, 0x33)
+    d_coeff = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_q = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_dq = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_eob = torch.full((n_tu,), -1, dtype=torch.int16, device="cuda:0")
+    d_en = torch.full((n_tu,), -1, dtype=torch.int64, device="cuda:0")
+    d_dist = torch.full((n_tu, 2), -1, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.encode_tu_batch_dev(d_src.data_ptr(), d_pred.data_ptr(), d_recon.data_ptr(), d_desc.data_ptr(), n_tu, w, h, d_qp.data_ptr(),
+                                d_iscan.data_ptr(), d_coeff.data_ptr(), d_q.data_ptr(), d_dq.data_ptr(), d_eob.data_ptr(),
+                                d_en.data_ptr(), d_dist.data_ptr())
+    hip_ctx.synchronize()
+    assert np.array_equal(d_coeff.cpu().numpy(), ref["coeff"])
+    assert np.array_equal(d_q.cpu().numpy(), ref["qcoeff"])
+    assert np.array_equal(d_dq.cpu().numpy(), ref["dqcoeff"])
+    assert np.array_equal(d_eob.cpu().numpy().view(np.uint16), ref["eob"])
+    assert np.array_equal(d_en.cpu().numpy().view(np.uint64), ref["energy"])
+    assert np.array_equal(d_dist.cpu().numpy().view(np.uint64), ref["dist"])
+    got = d_recon.cpu().numpy()
+    if in_place:
+        assert np.array_equal(got, ref["recon"])
+    else:   # only the TU areas are written
+        mask = np.zeros(got.size, bool)
+        for d in b["desc"]:
+            for r in range(h):
+                o = int(d["recon_offset"]) + r * int(d["recon_stride"]); mask[o:o + w] = True
+        assert np.array_equal(got[mask], ref["recon"][mask]) and (got[~mask] == 0x33).all()
+    assert (ref["eob"] > 0).any() and (ref["eob"] == 0).any()      # both branches of the reference's "has coefficients" test
+
+
+def test_encode_tu_optional_outputs_may_be_null(hip_ctx, oracle):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(11)
+    b = random_encode_batch(rng, 40, 16, 16)
+    ref = oracle_encode_batch(oracle, b)
+    d_src, d_pred, d_desc, d_qp, d_iscan = _dev(b["src"]), _dev(b["pred"]), _dev(b["desc"]), _dev(b["qparams"]), _dev(b["iscan"])
+    d_q = torch.zeros(40 * 256, dtype=torch.int32, device="cuda:0")
+    d_eob = torch.zeros(40, dtype=torch.int16, device="cuda:0")
+    hip_ctx.encode_tu_batch_dev(d_src.data_ptr(), d_pred.data_ptr(), d_pred.data_ptr(), d_desc.data_ptr(), 40, 16, 16, d_qp.data_ptr(),
+                                d_iscan.data_ptr(), None, d_q.data_ptr(), None, d_eob.data_ptr(), None, None)
+    hip_ctx.synchronize()
+    assert np.array_equal(d_q.cpu().numpy(), ref["qcoeff"])
+    assert np.array_equal(d_pred.cpu().numpy(), ref["recon"])

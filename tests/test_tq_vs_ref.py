@@ -221,3 +221,55 @@ def test_inv_txfm2d_residual_matches_reference(oracle, reftq, n):
             f(coeff.ctypes.data, n, ro.ctypes.data, n, tx_type, bd)
             orc(coeff.ctypes.data, n, n, n, tx_type, bd, oo.ctypes.data, n)
             assert np.array_equal(oo, ro), (n, tx_type, trial, np.flatnonzero(oo != ro)[:6])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# glue: 64-point packing / energy, distortion, residual
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(64, 64), (64, 32), (32, 64), (64, 16), (16, 64)])
+def test_pack_transform_matches_reference(oracle, reftq, size):
+    w, h = size
+    f = getattr(reftq, f"HandleTransform{w}x{h}_c")
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_uint32]
+    orc = oracle.lib.orc_pack_transform
+    orc.restype = C.c_uint64
+    orc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(w + h)
+    win, hin = min(w, 32), min(h, 32)
+    for trial in range(8):
+        full = rng.integers(-(1 << 20), 1 << 20, w * h).astype(np.int32)
+        ref = full.copy()
+        e_ref = f(ref.ctypes.data, w)
+        packed = np.zeros(win * hin, np.int32)
+        e_orc = orc(full.ctypes.data, w, h, packed.ctypes.data)
+        assert e_orc == e_ref
+        kept = ref.reshape(h, w)[:hin, :win]                           # what Av1EstimateTransform's memcpy loop re-packs
+        assert np.array_equal(packed.reshape(hin, win), kept)
+        assert not ref.reshape(h, w)[:, win:].any() and not ref.reshape(h, w)[hin:].any()
+
+
+def test_full_distortion_and_residual_match_reference(oracle, reftq):
+    fd = reftq.FullDistortionKernel32Bits
+    fd.restype = None
+    fd.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    od = oracle.lib.orc_full_distortion
+    od.restype = None
+    od.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for n in (4, 8, 16, 32):
+        a = rng.integers(-(1 << 22), 1 << 22, n * n).astype(np.int32)
+        b = rng.integers(-(1 << 22), 1 << 22, n * n).astype(np.int32)
+        r = np.zeros(2, np.uint64); o = np.zeros(2, np.uint64)
+        fd(a.ctypes.data, n, b.ctypes.data, n, r.ctypes.data, n, n)
+        od(a.ctypes.data, b.ctypes.data, n * n, o.ctypes.data)
+        assert np.array_equal(r, o)
+    rk = reftq.ResidualKernel_c
+    rk.restype = None
+    rk.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    for n in (4, 8, 16, 32, 64):
+        s = rng.integers(0, 256, (n, n + 5)).astype(np.uint8)
+        p = rng.integers(0, 256, (n, n + 3)).astype(np.uint8)
+        out = np.zeros((n, n), np.int16)
+        rk(s.ctypes.data, n + 5, p.ctypes.data, n + 3, out.ctypes.data, n, n, n)
+        assert np.array_equal(out, s[:, :n].astype(np.int16) - p[:, :n].astype(np.int16))

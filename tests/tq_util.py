@@ -146,3 +146,55 @@ def oracle_itxfm_batch(oracle, b):
         orc(b["coeff"].ctypes.data + 4 * int(d["coeff_offset"]), rec.ctypes.data + 2 * int(d["recon_offset"]), int(d["recon_stride"]),
             b["w"], b["h"], int(d["tx_type"]), b["bit_depth"])
     return rec.astype(b["pred"].dtype)
+
+
+def random_encode_batch(rng, n_tu, w, h, pic_w=512, pic_h=256):
+    """Source / prediction planes and TU descriptors for the fused encode chain; TUs do not overlap."""
+    win, hin = min(w, 32), min(h, 32)
+    n = win * hin
+    yy, xx = np.mgrid[0:pic_h, 0:pic_w]
+    base = 128 + 70 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    src = np.clip(base + rng.normal(0, 6, (pic_h, pic_w)), 0, 255).astype(np.uint8)
+    pred = np.clip(base + rng.normal(0, 10, (pic_h, pic_w)) + 8 * np.sin(xx / 3.0), 0, 255).astype(np.uint8)
+    pred[: pic_h // 8] = rng.integers(0, 256, (pic_h // 8, pic_w))            # large residuals
+    pred[-pic_h // 4:] = src[-pic_h // 4:]                                     # zero residuals -> eob 0
+    per_row = pic_w // w
+    slots = rng.permutation(per_row * (pic_h // h))[:n_tu]
+    n_rows = 8
+    qparams = np.stack([make_qparams(int(rng.integers(4, 400)), int(rng.integers(4, 500))) for _ in range(n_rows)])
+    scans, iscans = [], []
+    for v in range(3):
+        sc = rng.permutation(n).astype(np.int16)
+        isc = np.zeros(n, np.int16); isc[sc] = np.arange(n, dtype=np.int16)
+        scans.append(sc); iscans.append(isc)
+    types = svtav1_hip.valid_tx_types(w, h)
+    desc = np.zeros(n_tu, dtype=svtav1_hip.TU_DESC_DTYPE)
+    for i in range(n_tu):
+        sx, sy = int(slots[i]) % per_row, int(slots[i]) // per_row
+        off = sy * h * pic_w + sx * w
+        desc[i]["src_offset"] = off; desc[i]["pred_offset"] = off; desc[i]["recon_offset"] = off
+        desc[i]["coeff_offset"] = i * n; desc[i]["iscan_offset"] = int(rng.integers(0, 3)) * n
+        desc[i]["src_stride"] = pic_w; desc[i]["pred_stride"] = pic_w; desc[i]["recon_stride"] = pic_w
+        desc[i]["qparam_index"] = int(rng.integers(0, n_rows)); desc[i]["tx_type"] = types[int(rng.integers(0, len(types)))]
+    return {"src": src.reshape(-1), "pred": pred.reshape(-1), "desc": desc, "qparams": qparams, "scan": np.concatenate(scans),
+            "iscan": np.concatenate(iscans), "w": w, "h": h, "n": n}
+
+
+def oracle_encode_batch(oracle, b):
+    orc = oracle.lib.orc_encode_tu
+    orc.restype = None
+    orc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
+    n_tu, n = len(b["desc"]), b["n"]
+    out = {"recon": b["pred"].copy(), "coeff": np.zeros(n_tu * n, np.int32), "qcoeff": np.zeros(n_tu * n, np.int32),
+           "dqcoeff": np.zeros(n_tu * n, np.int32), "eob": np.zeros(n_tu, np.uint16), "energy": np.zeros(n_tu, np.uint64),
+           "dist": np.zeros((n_tu, 2), np.uint64)}
+    for i, d in enumerate(b["desc"]):
+        co = int(d["coeff_offset"])
+        qp = np.ascontiguousarray(b["qparams"][int(d["qparam_index"])])
+        sc = np.ascontiguousarray(b["scan"][int(d["iscan_offset"]):int(d["iscan_offset"]) + n])
+        orc(b["src"].ctypes.data + int(d["src_offset"]), int(d["src_stride"]), b["pred"].ctypes.data + int(d["pred_offset"]),
+            int(d["pred_stride"]), out["recon"].ctypes.data + int(d["recon_offset"]), int(d["recon_stride"]), b["w"], b["h"],
+            int(d["tx_type"]), qp.ctypes.data, sc.ctypes.data, out["coeff"].ctypes.data + 4 * co, out["qcoeff"].ctypes.data + 4 * co,
+            out["dqcoeff"].ctypes.data + 4 * co, out["eob"].ctypes.data + 2 * i, out["energy"].ctypes.data + 8 * i,
+            out["dist"].ctypes.data + 16 * i)
+    return out
