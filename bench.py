@@ -25,7 +25,6 @@ import numpy as np  # noqa: E402
 
 W, H = 1920, 1080
 PICTURES_PER_STEP = 12
-HME_STREAMS = 6
 SEARCH_W = SEARCH_H = 64
 ALGO_BYTES_PER_BLOCK = 4096 + 127 * 127 + 680  # src + ref window + results = 20905 B
 ABSDIFF_PER_BLOCK = SEARCH_W * SEARCH_H * 2048  # 64 8x8 SADs x 32 abs-diffs per position
@@ -145,32 +144,17 @@ def main():
     ctx = svtav1_hip.Context(local_rank)
     a = (d_pool.data_ptr(), stride, d_pool.data_ptr(), stride, d_desc.data_ptr(), n_blocks, SEARCH_W, SEARCH_H,
          d_sad.data_ptr(), d_mv.data_ptr())
-    # One context (stream) per ME worker, like the reference's per-thread MeContext_t: the per-picture
-    # search-centre launches are small (510 workgroups) and overlap across streams.
-    workers = [svtav1_hip.Context(local_rank) for _ in range(HME_STREAMS)]
-    w_streams = [torch.cuda.ExternalStream(w.stream, device=dev) for w in workers]
-    main_stream = torch.cuda.ExternalStream(ctx.stream, device=dev)
-    done = [torch.cuda.Event() for _ in workers]
-    start = torch.cuda.Event()
+    curs = [pdesc[i + 1] for i in range(PICTURES_PER_STEP)]
+    refs = [pdesc[i] for i in range(PICTURES_PER_STEP)]
 
     def step():
-        # hierarchical ME of every picture of the batch: search-centre kernel per picture (its descriptors land
-        # in the shared array), then ONE full-pel launch over all 510*P superblocks
+        # hierarchical ME of every picture of the batch: ONE search-centre launch over the 510*P superblocks (its
+        # descriptors land in d_desc), then ONE full-pel launch over the same superblocks, both on the context's stream
         if not args.no_hme:
-            start.record(main_stream)
-            for k, w in enumerate(workers):
-                w_streams[k].wait_event(start)  # previous step's full-pel launch has consumed d_desc
-            for i in range(PICTURES_PER_STEP):
-                workers[i % HME_STREAMS].hme_search_center_dev(d_pool.data_ptr(), pdesc[i + 1], pdesc[i], params, 0,
-                                                               d_sb.data_ptr(), n_sb, None, d_desc.data_ptr() + i * n_sb * 24)
-            for k, w in enumerate(workers):
-                done[k].record(w_streams[k])
-                main_stream.wait_event(done[k])
+            ctx.hme_search_center_batch_dev(d_pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_sb, None, d_desc.data_ptr())
         ctx.fullpel_search_dev(*a)
 
     def sync():
-        for w in workers:
-            w.synchronize()
         ctx.synchronize()
         torch.cuda.synchronize()
 
@@ -232,8 +216,6 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pool, stride, desc)
         print(json.dumps(out), flush=True)
-    for w in workers:
-        w.close()
     ctx.close()
     if distributed:
         dist.destroy_process_group()

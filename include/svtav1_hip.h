@@ -142,13 +142,24 @@ typedef struct svthip_sb_origin {
  * Outputs: d_desc[n_sb] (ready for svthip_me_fullpel_search_dev with the SAME pool as both planes),
  *          d_center[n_sb] = (int16 x, int16 y) final search centre, for inspection (may be NULL).
  * `cur`, `ref`, `params` are HOST structs (passed by value to the kernel); d_* are device pointers.
- * The pool must stay readable 4 bytes past the end of every plane (unaligned dword loads). */
+ * The pool must stay readable 64 bytes past the end of its last plane (windows are staged with aligned 16-byte groups). */
 #define SVTHIP_HME_STATE_INT16 25
+#define SVTHIP_HME_MAX_JOBS 32
 int32_t svthip_me_hme_search_center_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
                                         const svthip_pa_picture *ref, const svthip_me_params *params,
                                         uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
                                         const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
                                         int16_t *d_center, int16_t *d_hme_state, void *stream);
+
+/* The same for n_jobs (current, reference) picture pairs of equal size in ONE launch (a segment of pictures handed to the ME
+ * stage together): `cur` / `ref` are HOST arrays of n_jobs descriptors; every per-SB device array holds the jobs back to back,
+ * job j's SB i at index j * n_sb + i (d_desc, d_center, d_hme_state, d_l0_best_mv64 * l0_mv_stride).  One launch keeps all
+ * 256 CUs busy where a single 1080p picture (510 workgroups) cannot. */
+int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                              const svthip_pa_picture *ref, uint32_t n_jobs, const svthip_me_params *params,
+                                              uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
+                                              const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
+                                              int16_t *d_center, int16_t *d_hme_state, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sub-pel refinement (half-pel then quarter-pel) of the 85 square PUs of a batch of superblocks, one list.

@@ -93,13 +93,16 @@ __device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, c
     const uint32_t ndw = (W + 3) >> 2;
     const uint32_t tail = W & 3u;
     const uint32_t tailmask = tail ? ((1u << (8 * tail)) - 1u) : 0xffffffffu;
+#pragma unroll 1
     for (int pos = lane; pos < npos; pos += 64) {
         const int y = pos / sw, x = pos - y * sw;
         const uint8_t* r0 = ref + (size_t)y * ref_stride_raw + x;
         uint32_t acc = 0;
+#pragma unroll 1
         for (uint32_t r = 0; r < H; r++) {
             const uint8_t* sp = src + (size_t)r * src_stride;
             const uint8_t* rp = r0 + (size_t)r * ref_stride;
+#pragma unroll 2
             for (uint32_t c = 0; c < ndw; c++) {
                 uint32_t s = ldu32(sp + 4 * c);
                 uint32_t t = ldu32(rp + 4 * c);
@@ -121,6 +124,26 @@ __device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, c
 }
 
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS.  Every lane has 8
+// independent (aligned-pair) loads in flight: the copy is latency-bound otherwise.  Reads up to pitch*4 + 7 bytes per row.
+__device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t ref_stride_raw, int wrows, int pitch, uint32_t* win,
+                                                  int lane)
+{
+    const int total = wrows * pitch;
+    const uint32_t inv_pitch = (1u << 20) / (uint32_t)pitch + 1u;  // i / pitch == (i * inv) >> 20 for i < 2^20 / pitch
+    for (int i0 = 0; i0 < total; i0 += 512) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = min(i0 + k * 64 + lane, total - 1);  // clamped, branch-free
+            const int r = (int)(((uint32_t)i * inv_pitch) >> 20), c = i - r * pitch;
+            v[k] = ldu32_nb(base + (uint32_t)r * ref_stride_raw + 4u * (uint32_t)c);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) win[min(i0 + k * 64 + lane, total - 1)] = v[k];
+    }
+}
 
 // SadLoopKernel by one wave for the full-SB block shapes (W = 16 / 32 / 64 px, H rows taken every second plane
 // row), LDS-staged:
@@ -171,24 +194,7 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     for (int y0 = 0; y0 < sh; y0 += band) {
         const int bh = min(band, sh - y0);
         const int wrows = bh + 2 * H - 2;
-        // stage window rows y0 .. y0+wrows-1 (plane rows), pitch dwords each
-        {
-            // every lane has 8 independent (aligned-pair) loads in flight: the copy is latency-bound otherwise
-            const uint8_t* base = ref + (size_t)y0 * ref_stride_raw;
-            const int total = wrows * pitch;
-            const uint32_t inv_pitch = (1u << 20) / (uint32_t)pitch + 1u;  // i / pitch == (i * inv) >> 20 for i < 2^20 / pitch
-            for (int i0 = 0; i0 < total; i0 += 512) {
-                uint32_t v[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int i = min(i0 + k * 64 + lane, total - 1);  // clamped, branch-free
-                    const int r = (int)(((uint32_t)i * inv_pitch) >> 20), c = i - r * pitch;
-                    v[k] = ldu32_nb(base + (uint32_t)r * ref_stride_raw + 4u * (uint32_t)c);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) win[min(i0 + k * 64 + lane, total - 1)] = v[k];
-            }
-        }
+        stage_window_rows(ref + (size_t)y0 * ref_stride_raw, ref_stride_raw, wrows, pitch, win, lane);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -259,6 +265,81 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
 }
 
+// SadLoopKernel of HME level 0 (16 x 8-row block on the 1/16 plane; ~70 % of the search-centre work), one wave.
+// An item is 16 consecutive search positions of one search row = 16 bytes = one ds_read_b128 step along the window, so lane
+// i of a row reads window dwords 4i .. 4i+7 with two conflict-free b128 loads per block row and issues 16 v_qsad_pk_u16_u8
+// (4 source dwords x 4 position groups); the 8 block rows are fully unrolled so every LDS offset is an immediate or a
+// scalar multiple of the pitch.  A 16x8 SAD is < 2^16 and the area has < 2^16 positions, so the best position is a 32-bit
+// (sad << 16 | raster index) minimum, which is the reference's strict-'<' raster rule.
+__device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride_raw, int sw, int sh,
+                                 int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad, int* bx, int* by)
+{
+    constexpr int H = 8, WD = 4;
+    uint32_t* srcbuf = reinterpret_cast<uint32_t*>(lds);  // [8][4]
+    const int nit = (sw + 15) >> 4;                       // items per search row
+    const int pitch = 4 * nit + 4;                        // window dwords per row (multiple of 4: items stay 16-byte aligned)
+    uint32_t* win = srcbuf + H * WD;
+    const int avail_rows = (lds_bytes / 4 - H * WD) / pitch;
+    int band = avail_rows - (2 * H - 2);
+    if (band > sh) band = sh;
+    if (band < 1 || sw * sh > 65536) {
+        wave_sad_loop_lds<16>(src, src_stride, ref, ref_stride_raw, H, sw, sh, lane, lds, lds_bytes, best_sad, bx, by);
+        return;
+    }
+    if (lane < H * WD) srcbuf[lane] = ldu32_nb(src + (uint32_t)(lane >> 2) * src_stride + 4u * (uint32_t)(lane & 3));
+    uint32_t best = 0xffffffffu;
+    const uint32_t inv_nit = (1u << 20) / (uint32_t)nit + 1u;
+    for (int y0 = 0; y0 < sh; y0 += band) {
+        const int bh = min(band, sh - y0);
+        stage_window_rows(ref + (size_t)y0 * ref_stride_raw, ref_stride_raw, bh + 2 * H - 2, pitch, win, lane);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int nitems = nit * bh;
+        for (int it0 = 0; it0 < nitems; it0 += 64) {
+            const int item = min(it0 + lane, nitems - 1);
+            const bool valid = it0 + lane < nitems;
+            const int iy = (int)(((uint32_t)item * inv_nit) >> 20), io = item - iy * nit;
+            const uint32_t* w0 = win + iy * pitch + 4 * io;
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < H; r++) {
+                const uint32_t* wr = w0 + 2 * r * pitch;
+                const uint4 da = *reinterpret_cast<const uint4*>(wr);
+                const uint4 db = *reinterpret_cast<const uint4*>(wr + 4);
+                const uint4 sv = *reinterpret_cast<const uint4*>(srcbuf + r * WD);
+                const uint32_t d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+                const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                for (int c = 0; c < WD; c++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        acc[g] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(d[c + g], d[c + g + 1]), s4[c], acc[g]);
+            }
+            // 16 keys: (sad << 16) + raster index; positions beyond the search width and padding lanes never win
+            const int xs0 = 16 * io;
+            const uint32_t base = (uint32_t)((y0 + iy) * sw + xs0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t lo = (uint32_t)acc[g], hi = (uint32_t)(acc[g] >> 32);
+                const uint32_t sad4[4] = {lo << 16, lo & 0xffff0000u, hi << 16, hi & 0xffff0000u};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int xs = xs0 + 4 * g + j;
+                    const uint32_t key = (valid && xs < sw) ? (sad4[j] + base + (uint32_t)(4 * g + j)) : 0xffffffffu;
+                    best = min(best, key);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
+    const uint32_t pos = best & 0xffffu;
+    *best_sad = best >> 16;
+    *by = (int)(pos / (uint32_t)sw);
+    *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
+}
+
 __device__ __forceinline__ void clamp_center(int& x, int& y, int ox, int oy, int pw, int ph)
 {
     // int16 semantics of the reference hold: every intermediate fits 16 bits for pictures <= 8K
@@ -289,7 +370,7 @@ __device__ __forceinline__ int round_hme_width(int w)
     return (w < 8) ? 8 : ((w & 7) ? (w + (w - ((w >> 3) << 3))) : w);  // :4528 (adds the remainder, sic)
 }
 
-constexpr int kHmeLdsPerWave = 12 * 1024;  // per-wave LDS slice: source block + a band of the search window
+constexpr int kHmeLdsPerWave = 8 * 1024;  // per-wave LDS slice: source block + a band of the search window
 
 struct HmeShared {
     unsigned long long cost[8];   // centre-check candidate costs
@@ -300,9 +381,8 @@ struct HmeShared {
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_picture cur,
-                                                         svthip_pa_picture ref, svthip_me_params P, uint32_t list_index,
-                                                         const svthip_sb_origin* __restrict__ sbs,
+__global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P,
+                                                         uint32_t list_index, const svthip_sb_origin* __restrict__ sbs,
                                                          const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
                                                          svthip_fullpel_desc* __restrict__ out_desc,
                                                          int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state)
@@ -312,8 +392,11 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* wlds = hme_lds + wave * kHmeLdsPerWave;
-    const uint32_t sbi = blockIdx.x;
-    const int ox = sbs[sbi].x, oy = sbs[sbi].y;
+    // blockIdx.y = job (one current/reference picture pair); all per-SB inputs and outputs of job j live at [j * n_sb + i]
+    const svthip_pa_picture cur = jobs.cur[blockIdx.y], ref = jobs.ref[blockIdx.y];
+    const uint32_t sb_local = blockIdx.x;
+    const uint32_t sbi = blockIdx.y * gridDim.x + sb_local;
+    const int ox = sbs[sb_local].x, oy = sbs[sb_local].y;
     const int pw = cur.width, ph = cur.height;
     const uint32_t sb_w = (uint32_t)min(64, pw - ox), sb_h = (uint32_t)min(64, ph - oy);
     const int nw = P.number_hme_search_region_in_width, nh = P.number_hme_search_region_in_height;
@@ -383,8 +466,8 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                     const uint8_t* r = pool + ref.sixteenth_offset + (size_t)(16 + o_y + yo) * ref.sixteenth_stride + 16 + o_x + xo;
                     int bx, by;
                     if (sb_w == 64)
-                        wave_sad_loop_lds<16>(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride, 8, sw, shh, lane, wlds,
-                                              kHmeLdsPerWave, &sad0, &bx, &by);
+                        wave_sad_loop_l0(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride, sw, shh, lane, wlds, kHmeLdsPerWave, &sad0,
+                                         &bx, &by);
                     else
                         wave_sad_loop_generic(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride * 2, (sb_h >> 2) >> 1, sb_w >> 2,
                                               ref.sixteenth_stride, sw, shh, lane, &sad0, &bx, &by);

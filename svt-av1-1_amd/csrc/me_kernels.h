@@ -22,10 +22,14 @@ __global__ void fullpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t
                                  const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
                                  uint32_t* __restrict__ out_mv);
 
-__global__ void hme_center_kernel(const uint8_t* __restrict__ pool, svthip_pa_picture cur, svthip_pa_picture ref,
-                                  svthip_me_params P, uint32_t list_index, const svthip_sb_origin* __restrict__ sbs,
-                                  const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
-                                  svthip_fullpel_desc* __restrict__ out_desc,
+// job table of one search-centre launch, passed by value in the kernel arguments (2.5 KB)
+struct HmeJobTable {
+    svthip_pa_picture cur[SVTHIP_HME_MAX_JOBS];
+    svthip_pa_picture ref[SVTHIP_HME_MAX_JOBS];
+};
+__global__ void hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P, uint32_t list_index,
+                                  const svthip_sb_origin* __restrict__ sbs, const uint32_t* __restrict__ l0_best_mv64,
+                                  uint32_t l0_mv_stride, svthip_fullpel_desc* __restrict__ out_desc,
                                   int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,

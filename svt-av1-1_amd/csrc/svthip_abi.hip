@@ -270,14 +270,14 @@ int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const 
     return SVTHIP_OK;
 }
 
-int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                        const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
-                                        const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,
-                                        uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc, int16_t* d_center,
-                                        int16_t* d_hme_state, void* stream)
+int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                              const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
+                                              uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
+                                              const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
+                                              int16_t* d_center, int16_t* d_hme_state, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
-    if (n_sb == 0) return SVTHIP_OK;
+    if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
     if (!d_pool || !cur || !ref || !params || !d_sb || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (list_index > 1) return fail(SVTHIP_ERR_BAD_PARAMETER, "list_index must be 0 or 1%s", "");
     if (list_index == 1 && !d_l0_best_mv64 && params->temporal_layer_index > 0)
@@ -286,18 +286,45 @@ int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, 
     if (P.number_hme_search_region_in_width < 1 || P.number_hme_search_region_in_width > 2 ||
         P.number_hme_search_region_in_height < 1 || P.number_hme_search_region_in_height > 2)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "HME search regions must be 1..2 per axis%s", "");
-    if ((cur->width & 7) || (cur->height & 7) || cur->width != ref->width || cur->height != ref->height)
-        return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be equal multiples of 8%s", "");
-    if ((cur->full_stride & 3u) || (ref->full_stride & 3u) || (cur->full_offset & 3))
-        return fail(SVTHIP_ERR_BAD_PARAMETER, "full-resolution strides / current-plane offset must be multiples of 4%s", "");
-    const int64_t max_off = (cur->full_offset > ref->full_offset ? cur->full_offset : ref->full_offset) +
-                            (int64_t)(cur->height + 136) * (cur->full_stride > ref->full_stride ? cur->full_stride : ref->full_stride);
-    if (max_off > 0x7fffffffLL) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture pool offsets must fit 31 bits%s", "");
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const svthip_pa_picture *c = cur + j, *r = ref + j;
+        if ((c->width & 7) || (c->height & 7) || c->width != r->width || c->height != r->height || c->width != cur->width ||
+            c->height != cur->height)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be equal multiples of 8%s (job %d)", "", (int)j);
+        if ((c->full_stride & 3u) || (r->full_stride & 3u) || (c->full_offset & 3))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "full-resolution strides / current-plane offset must be multiples of 4%s (job %d)", "",
+                        (int)j);
+        const int64_t max_off = (c->full_offset > r->full_offset ? c->full_offset : r->full_offset) +
+                                (int64_t)(c->height + 136) * (c->full_stride > r->full_stride ? c->full_stride : r->full_stride);
+        if (max_off > 0x7fffffffLL) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture pool offsets must fit 31 bits%s (job %d)", "", (int)j);
+    }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb), dim3(256), 0, s, d_pool, *cur, *ref, P, list_index, d_sb,
-                       d_l0_best_mv64, l0_mv_stride ? l0_mv_stride : 1u, d_desc, d_center, d_hme_state);
-    HIP_TRY(hipGetLastError());
+    const uint32_t mvs = l0_mv_stride ? l0_mv_stride : 1u;
+    for (uint32_t j0 = 0; j0 < n_jobs; j0 += SVTHIP_HME_MAX_JOBS) {
+        const uint32_t nj = (n_jobs - j0 < SVTHIP_HME_MAX_JOBS) ? n_jobs - j0 : SVTHIP_HME_MAX_JOBS;
+        svthip::HmeJobTable jt;
+        memset(&jt, 0, sizeof(jt));
+        for (uint32_t j = 0; j < nj; j++) {
+            jt.cur[j] = cur[j0 + j];
+            jt.ref[j] = ref[j0 + j];
+        }
+        const size_t base = (size_t)j0 * n_sb;
+        hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb,
+                           d_l0_best_mv64 ? d_l0_best_mv64 + base * mvs : nullptr, mvs, d_desc + base,
+                           d_center ? d_center + 2 * base : nullptr, d_hme_state ? d_hme_state + SVTHIP_HME_STATE_INT16 * base : nullptr);
+        HIP_TRY(hipGetLastError());
+    }
     return SVTHIP_OK;
+}
+
+int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                        const svthip_pa_picture* ref, const svthip_me_params* params, uint32_t list_index,
+                                        const svthip_sb_origin* d_sb, uint32_t n_sb, const uint32_t* d_l0_best_mv64,
+                                        uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc, int16_t* d_center,
+                                        int16_t* d_hme_state, void* stream)
+{
+    return svthip_me_hme_search_center_batch_dev(ctx, d_pool, cur, ref, 1, params, list_index, d_sb, n_sb, d_l0_best_mv64, l0_mv_stride,
+                                                 d_desc, d_center, d_hme_state, stream);
 }
 
 int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,

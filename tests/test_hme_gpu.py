@@ -134,3 +134,30 @@ def test_hme_1080p_default(hip_ctx, oracle):
     sample = np.random.default_rng(5).choice(sb.shape[0], 40, replace=False)
     s0, m0 = oracle.fullpel_search_batch(pool, pool, d0[sample], descs[0].full_stride, descs[1].full_stride)
     assert np.array_equal(dev[0][2][sample], s0) and np.array_equal(dev[0][3][sample], m0)
+
+
+def test_batched_launch_equals_per_picture_launches(hip_ctx):
+    """svthip_me_hme_search_center_batch_dev over several picture pairs == one svthip_me_hme_search_center_dev per pair."""
+    import torch
+    from svtav1_hip import synth
+
+    w, h, n_pic = 320, 192, 5
+    pics = [synth.PaPicture(synth.synth_luma(w, h, 2 * i)) for i in range(n_pic + 1)]
+    pool, pd = svtav1_hip.build_picture_pool(pics)
+    d_pool = torch.from_numpy(pool).to("cuda:0")
+    sbs = svtav1_hip.sb_origins(w, h)
+    n_sb = sbs.shape[0]
+    d_sb = torch.from_numpy(sbs.view(np.int16).copy()).to("cuda:0")
+    params = svtav1_hip.default_me_params(w, h, 3, 0)
+    d_one = torch.zeros((n_pic * n_sb, 6), dtype=torch.int32, device="cuda:0")
+    d_cen1 = torch.zeros((n_pic * n_sb, 2), dtype=torch.int16, device="cuda:0")
+    for i in range(n_pic):
+        hip_ctx.hme_search_center_dev(d_pool.data_ptr(), pd[i + 1], pd[i], params, 0, d_sb.data_ptr(), n_sb, None,
+                                      d_one.data_ptr() + i * n_sb * 24, d_cen1.data_ptr() + i * n_sb * 4)
+    d_bat = torch.zeros((n_pic * n_sb, 6), dtype=torch.int32, device="cuda:0")
+    d_cen2 = torch.zeros((n_pic * n_sb, 2), dtype=torch.int16, device="cuda:0")
+    hip_ctx.hme_search_center_batch_dev(d_pool.data_ptr(), [pd[i + 1] for i in range(n_pic)], [pd[i] for i in range(n_pic)], params, 0,
+                                        d_sb.data_ptr(), n_sb, None, d_bat.data_ptr(), d_cen2.data_ptr())
+    hip_ctx.synchronize()
+    assert torch.equal(d_one, d_bat) and torch.equal(d_cen1, d_cen2)
+    assert (d_cen2 != 0).any()
