@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="one fused search-centre + full-pel kernel instead of the two launches")
     ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
     args = ap.parse_args()
 
@@ -150,9 +151,14 @@ def main():
     def step():
         # hierarchical ME of every picture of the batch: ONE search-centre launch over the 510*P superblocks (its
         # descriptors land in d_desc), then ONE full-pel launch over the same superblocks, both on the context's stream
-        if not args.no_hme:
+        if args.no_hme:
+            ctx.fullpel_search_dev(*a)
+        elif not args.fused:
             ctx.hme_search_center_batch_dev(d_pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_sb, None, d_desc.data_ptr())
-        ctx.fullpel_search_dev(*a)
+            ctx.fullpel_search_dev(*a)
+        else:
+            ctx.integer_search_batch_dev(d_pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_sb, None, d_desc.data_ptr(),
+                                         d_sad.data_ptr(), d_mv.data_ptr())
 
     def sync():
         ctx.synchronize()

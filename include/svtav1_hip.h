@@ -161,6 +161,19 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx *ctx, const uint8_t *d_
                                               const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
                                               int16_t *d_center, int16_t *d_hme_state, void *stream);
 
+/* Search centres AND the 85-PU full-pel search of the same superblocks in one fused launch: MotionEstimateLcu from the
+ * centre check to the end of FullPelSearch_LCU (Source/Lib/Codec/EbMotionEstimation.c:6300-6760) for one reference list.
+ * Arguments as svthip_me_hme_search_center_batch_dev, plus d_best_sad / d_best_mv [n_jobs * n_sb][85] (the outputs of
+ * svthip_me_fullpel_search_dev run on the descriptors this call also writes to d_desc).  Bit-identical to the two
+ * separate calls; the descriptor stays in LDS and the latency-bound centre chain of one workgroup overlaps the VALU-bound
+ * full-pel search of its CU neighbours. */
+int32_t svthip_me_integer_search_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                           const svthip_pa_picture *ref, uint32_t n_jobs, const svthip_me_params *params,
+                                           uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
+                                           const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
+                                           int16_t *d_center, int16_t *d_hme_state, uint32_t *d_best_sad, uint32_t *d_best_mv,
+                                           void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sub-pel refinement (half-pel then quarter-pel) of the 85 square PUs of a batch of superblocks, one list.
  * Replaces InterpolateSearchRegionAVC + HalfPelSearch_LCU + QuarterPelSearch_LCU and the kernels behind them

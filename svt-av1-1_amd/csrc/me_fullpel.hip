@@ -27,57 +27,7 @@
 namespace svthip {
 
 namespace {
-
-constexpr int kPitch = SVTHIP_FULLPEL_LDS_PITCH;  // bytes per window row in LDS
-
-__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
-
-__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// keys for the four positions of a quad from packed u16 SADs (lo: slots 0,1  hi: slots 2,3)
-__device__ __forceinline__ uint32_t track4(uint32_t best, uint64_t acc, const uint32_t* idx, uint32_t himask)
-{
-    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
-    uint32_t k0 = (lo << 16) | idx[0];
-    uint32_t k1 = (lo & himask) | idx[1];
-    uint32_t k2 = (hi << 16) | idx[2];
-    uint32_t k3 = (hi & himask) | idx[3];
-    best = min3u(best, k0, k1);
-    best = min3u(best, k2, k3);
-    return best;
-}
-
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        uint32_t o = __shfl_xor(v, m);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        unsigned long long o = __shfl_xor(v, m);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ uint32_t mv_word(int x, int y)
-{
-    // (uint16)(4*y) << 16 | (uint16)(4*x), Codec/EbMotionEstimation.c:1389-1391
-    return ((uint32_t)(uint16_t)(y * 4) << 16) | (uint32_t)(uint16_t)(x * 4);
-}
-
+#include "me_fullpel_impl.h"
 }  // namespace
 
 __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kernel(
@@ -86,211 +36,7 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
     uint32_t* __restrict__ out_mv)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // LDS layout: [0,16K) exchange buffer for 32x32 sums, [16K,16K+16) 64x64 result, then the window.
-    uint32_t* xch = reinterpret_cast<uint32_t*>(smem);
-    unsigned long long* best64_lds = reinterpret_cast<unsigned long long*>(smem + 16384);
-    uint8_t* win = smem + 16384 + 64;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int Q = __builtin_amdgcn_readfirstlane(tid >> 6);  // quadrant = wave index
-    const int Qx = Q & 1, Qy = Q >> 1;
-
-    const int32_t* d = desc + 6 * blockIdx.x;
-    const int src_off = d[0];
-    const int ref_off = d[1];
-    const int xo = d[2], yo = d[3];
-    const int sw = d[4], sh = d[5];
-    const int n_xg = (sw + 15) >> 4;
-
-    // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
-    {
-        const uint8_t* base = ref_plane + ref_off;
-        const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 3u);
-        const uint32_t* base4 = reinterpret_cast<const uint32_t*>(base - a);
-        const int rows = sh + 63;
-        const int ndw_valid = (sw + 63 + 3) >> 2;
-        const int ndw_row = kPitch >> 2;
-        const int rstride4 = ref_stride >> 2;
-        const int total = rows * ndw_row;
-        for (int i = tid; i < total; i += 256) {
-            int r = i / ndw_row;
-            int c = i - r * ndw_row;
-            uint32_t v = 0;
-            if (c < ndw_valid) {
-                const uint32_t* p = base4 + (size_t)r * rstride4 + c;
-                uint32_t lo = p[0];
-                uint32_t hi = a ? p[1] : 0u;
-                v = __builtin_amdgcn_alignbyte(hi, lo, a);
-            }
-            reinterpret_cast<uint32_t*>(win)[i] = v;
-        }
-        if (tid == 0) *best64_lds = ~0ull;
-    }
-    __syncthreads();
-
-    // source pixels of this wave's quadrant (wave-uniform -> scalar loads)
-    const uint32_t* src4 = reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)(32 * Qy) * src_stride + 32 * Qx);
-    const int sstride4 = src_stride >> 2;
-
-    uint32_t best8[16], best16[4], best32 = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < 16; i++) best8[i] = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < 4; i++) best16[i] = 0xffffffffu;
-    uint32_t best64_raw = 0xffffffffu, best64_idx = 0;
-
-    const uint32_t himask = 0xffff0000u;
-    const int n_items = n_xg * sh;
-    const int n_iter = (n_items + 63) >> 6;
-
-    for (int it = 0; it < n_iter; it++) {
-        int pg = it * 64 + lane;
-        const bool lane_valid = pg < n_items;
-        if (!lane_valid) pg = 0;
-        const int y = pg / n_xg;
-        const int xg = pg - y * n_xg;
-
-        // per-position raster index; positions outside the search area get idx = ~0 so that every key
-        // OR-ed with it is 0xffffffff and can never win (at least one position is always valid)
-        uint32_t idx[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int x = 16 * xg + i;
-            idx[i] = (lane_valid && x < sw) ? (uint32_t)(y * 128 + x) : 0xffffffffu;
-        }
-
-        uint32_t s16lo[4][4], s16hi[4][4];  // [zz][q] packed u16 16x16 sums
-
-        const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
-
-#pragma unroll
-        for (int zz = 0; zz < 4; zz++) {
-            const int C = zz & 1, R = zz >> 1;
-            uint64_t acc[4][4];
-
-#pragma unroll
-            for (int r8 = 0; r8 < 8; r8++) {
-                const uint8_t* p = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
-                const uint4 A = *reinterpret_cast<const uint4*>(p);
-                const uint4 B = *reinterpret_cast<const uint4*>(p + 16);
-                const uint32_t W[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-                const uint32_t* srow = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
-                uint32_t S[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) S[h] = srow[h];  // uniform address, read-only -> s_load_dwordx4
-                const int krow = (r8 >> 2) * 2;
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int h = 0; h < 4; h++) {
-                        const int k = krow + (h >> 1);
-                        const bool first = ((r8 & 3) == 0) && ((h & 1) == 0);  // first touch of acc[k][q]
-                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(W[q + h], W[q + h + 1]), S[h],
-                                                                    first ? 0ull : acc[k][q]);
-                    }
-            }
-
-            // 8x8 PUs of this 16x16
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) best8[4 * zz + k] = track4(best8[4 * zz + k], acc[k][q], &idx[4 * q], himask);
-
-            // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t lo = (uint32_t)acc[0][q] + (uint32_t)acc[1][q] + (uint32_t)acc[2][q] + (uint32_t)acc[3][q];
-                const uint32_t hi = (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32) +
-                                    (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32);
-                best16[zz] = track4(best16[zz], pack64(lo, hi), &idx[4 * q], himask);
-                s16lo[zz][q] = lo;
-                s16hi[zz][q] = hi;
-            }
-        }
-
-        // 32x32 = sum of the four 16x16: pairs are added packed (<= 2*32640 fits u16), then widened
-        uint32_t s32acc[16];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t a_lo = s16lo[0][q] + s16lo[1][q], b_lo = s16lo[2][q] + s16lo[3][q];
-            const uint32_t a_hi = s16hi[0][q] + s16hi[1][q], b_hi = s16hi[2][q] + s16hi[3][q];
-            s32acc[4 * q + 0] = (a_lo & 0xffffu) + (b_lo & 0xffffu);
-            s32acc[4 * q + 1] = (a_lo >> 16) + (b_lo >> 16);
-            s32acc[4 * q + 2] = (a_hi & 0xffffu) + (b_hi & 0xffffu);
-            s32acc[4 * q + 3] = (a_hi >> 16) + (b_hi >> 16);
-        }
-
-        // 32x32 PU of this quadrant: key = raw << 14 | idx  (raw <= 130560 < 2^17)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            uint32_t k0 = (s32acc[i] << 14) | idx[i];
-            uint32_t k1 = (s32acc[i + 1] << 14) | idx[i + 1];
-            best32 = min3u(best32, k0, k1);
-        }
-
-        // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
-        __syncthreads();  // previous iteration's readers are done
-        {
-            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; q++) dst[q] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
-        }
-        __syncthreads();
-        {
-            uint4 s = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const uint4 v = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-            const uint32_t sv[4] = {s.x, s.y, s.z, s.w};
-            // idx of position 4Q+j of this lane: idx[] is indexed statically, so select by Q
-            const int xbase = 16 * xg + 4 * Q;
-            const uint32_t ibase = (uint32_t)(y * 128 + xbase);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // strict '<', positions visited in raster order per lane; positions outside the area never win
-                const bool better = (sv[j] < best64_raw) && lane_valid && (xbase + j < sw);
-                best64_raw = better ? sv[j] : best64_raw;
-                best64_idx = better ? (ibase + j) : best64_idx;
-            }
-        }
-    }
-
-    // ---- reduce across the wave and publish ----
-    uint32_t* osad = out_sad + (size_t)85 * blockIdx.x;
-    uint32_t* omv = out_mv + (size_t)85 * blockIdx.x;
-
-    uint32_t red[21];
-#pragma unroll
-    for (int i = 0; i < 16; i++) red[i] = wave_min_u32(best8[i]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) red[16 + i] = wave_min_u32(best16[i]);
-    red[20] = wave_min_u32(best32);
-    const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
-
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            const uint32_t key = red[i];
-            uint32_t raw, id;
-            int pu;
-            if (i < 16) { raw = key >> 16; id = key & 0x3fffu; pu = 21 + 16 * Q + i; }
-            else if (i < 20) { raw = key >> 16; id = key & 0x3fffu; pu = 5 + 4 * Q + (i - 16); }
-            else { raw = key >> 14; id = key & 0x3fffu; pu = 1 + Q; }
-            osad[pu] = 2u * raw;
-            omv[pu] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
-        }
-        atomicMin(best64_lds, k64);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long k = *best64_lds;
-        const uint32_t raw = (uint32_t)(k >> 32), id = (uint32_t)k;
-        osad[0] = 2u * raw;
-        omv[0] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
-    }
+    fullpel85_sb(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * blockIdx.x, blockIdx.x, out_sad, out_mv, smem);
 }
 
 }  // namespace svthip

@@ -38,6 +38,7 @@ struct svthip_ctx {
     void* scratch[6];
     size_t scratch_bytes[6];
     int max_dyn_lds_set;
+    int max_dyn_lds_search;
 };
 
 namespace {
@@ -270,15 +271,16 @@ int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const 
     return SVTHIP_OK;
 }
 
-int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                              const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
-                                              uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
-                                              const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
-                                              int16_t* d_center, int16_t* d_hme_state, void* stream)
+static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur, const svthip_pa_picture* ref,
+                                uint32_t n_jobs, const svthip_me_params* params, uint32_t list_index, const svthip_sb_origin* d_sb,
+                                uint32_t n_sb, const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
+                                int16_t* d_center, int16_t* d_hme_state, uint32_t* d_best_sad, uint32_t* d_best_mv, bool fused,
+                                void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
     if (!d_pool || !cur || !ref || !params || !d_sb || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (fused && (!d_best_sad || !d_best_mv)) return fail(SVTHIP_ERR_BAD_PARAMETER, "null result pointer%s", "");
     if (list_index > 1) return fail(SVTHIP_ERR_BAD_PARAMETER, "list_index must be 0 or 1%s", "");
     if (list_index == 1 && !d_l0_best_mv64 && params->temporal_layer_index > 0)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "list 1 needs the list-0 64x64 MVs (hme_mv_center_check direct candidate)%s", "");
@@ -286,6 +288,8 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_
     if (P.number_hme_search_region_in_width < 1 || P.number_hme_search_region_in_width > 2 ||
         P.number_hme_search_region_in_height < 1 || P.number_hme_search_region_in_height > 2)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "HME search regions must be 1..2 per axis%s", "");
+    if (fused && (P.search_area_width < 1 || P.search_area_height < 1))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be at least 1x1%s", "");
     for (uint32_t j = 0; j < n_jobs; j++) {
         const svthip_pa_picture *c = cur + j, *r = ref + j;
         if ((c->width & 7) || (c->height & 7) || c->width != r->width || c->height != r->height || c->width != cur->width ||
@@ -300,6 +304,16 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const uint32_t mvs = l0_mv_stride ? l0_mv_stride : 1u;
+    size_t lds = 0;
+    if (fused) {
+        const uint32_t shh = P.search_area_height > 127 ? 127u : P.search_area_height;  // the kernel clamps the area to 127 (:6667)
+        lds = svthip::me_search_lds_bytes(shh);
+        if ((int)lds > ctx->max_dyn_lds_search) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::me_search_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->max_dyn_lds_search = (int)lds;
+        }
+    }
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += SVTHIP_HME_MAX_JOBS) {
         const uint32_t nj = (n_jobs - j0 < SVTHIP_HME_MAX_JOBS) ? n_jobs - j0 : SVTHIP_HME_MAX_JOBS;
         svthip::HmeJobTable jt;
@@ -309,12 +323,39 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_
             jt.ref[j] = ref[j0 + j];
         }
         const size_t base = (size_t)j0 * n_sb;
-        hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb,
-                           d_l0_best_mv64 ? d_l0_best_mv64 + base * mvs : nullptr, mvs, d_desc + base,
-                           d_center ? d_center + 2 * base : nullptr, d_hme_state ? d_hme_state + SVTHIP_HME_STATE_INT16 * base : nullptr);
+        const uint32_t* mv64 = d_l0_best_mv64 ? d_l0_best_mv64 + base * mvs : nullptr;
+        int16_t* cen = d_center ? d_center + 2 * base : nullptr;
+        int16_t* st = d_hme_state ? d_hme_state + SVTHIP_HME_STATE_INT16 * base : nullptr;
+        if (fused)
+            hipLaunchKernelGGL(svthip::me_search_kernel, dim3(n_sb, nj), dim3(256), lds, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
+                               d_desc + base, cen, st, d_best_sad + 85 * base, d_best_mv + 85 * base);
+        else
+            hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
+                               d_desc + base, cen, st);
         HIP_TRY(hipGetLastError());
     }
     return SVTHIP_OK;
+}
+
+int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                              const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
+                                              uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
+                                              const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
+                                              int16_t* d_center, int16_t* d_hme_state, void* stream)
+{
+    return hme_batch_launch(ctx, d_pool, cur, ref, n_jobs, params, list_index, d_sb, n_sb, d_l0_best_mv64, l0_mv_stride, d_desc, d_center,
+                            d_hme_state, nullptr, nullptr, false, stream);
+}
+
+int32_t svthip_me_integer_search_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                           const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
+                                           uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
+                                           const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
+                                           int16_t* d_center, int16_t* d_hme_state, uint32_t* d_best_sad, uint32_t* d_best_mv,
+                                           void* stream)
+{
+    return hme_batch_launch(ctx, d_pool, cur, ref, n_jobs, params, list_index, d_sb, n_sb, d_l0_best_mv64, l0_mv_stride, d_desc, d_center,
+                            d_hme_state, d_best_sad, d_best_mv, true, stream);
 }
 
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
