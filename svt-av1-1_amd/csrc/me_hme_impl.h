@@ -47,6 +47,28 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 __device__ uint32_t wave_block_sad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride,
                                    uint32_t H, uint32_t W, int lane)
 {
+    if (W == 64 && (H & 3u) == 0) {
+        // full-width block: lane = (row mod 4, dword column), four rows per pass, all loads of a lane in flight together;
+        // src is dword aligned (SB origin multiple of 64), ref is re-aligned from aligned pairs
+        const uint32_t c = (uint32_t)lane & 15u, r0 = (uint32_t)lane >> 4;
+        const uint8_t* sp = src + (size_t)r0 * src_stride + 4u * c;
+        const uint8_t* rp = ref + (size_t)r0 * ref_stride + 4u * c;
+        uint32_t acc4 = 0;
+        for (uint32_t r = 0; r < H; r += 16) {
+            uint32_t sv[4], tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool in = r + 4u * (uint32_t)k < H;  // uniform
+                sv[k] = in ? *reinterpret_cast<const uint32_t*>(sp + (size_t)(4 * k) * src_stride) : 0u;
+                tv[k] = in ? ldu32_nb(rp + (size_t)(4 * k) * ref_stride) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc4 = __builtin_amdgcn_sad_u8(sv[k], tv[k], acc4);
+            sp += (size_t)16 * src_stride;
+            rp += (size_t)16 * ref_stride;
+        }
+        return wave_sum_u32(acc4);
+    }
     const uint32_t ndw = (W + 3) >> 2;
     const uint32_t n = H * ndw;
     uint32_t acc = 0;
@@ -107,11 +129,48 @@ __device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, c
 
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS.  Every lane has 8
-// independent (aligned-pair) loads in flight: the copy is latency-bound otherwise.  Reads up to pitch*4 + 7 bytes per row.
+// Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS (row r at
+// win + r * pitch).  Lane = (row group, dword column): a lane keeps its column and walks down the rows, 8 rows in flight, so
+// the per-dword cost is two address adds, the aligned-pair loads, one v_alignbyte and the LDS store.  Reads up to
+// pitch * 4 + 7 bytes per row.
 __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t ref_stride_raw, int wrows, int pitch, uint32_t* win,
                                                   int lane)
 {
+    if (pitch <= 64) {
+        const int cshift = pitch <= 16 ? 4 : (pitch <= 32 ? 5 : 6);
+        const int G = 64 >> cshift;                        // rows per wave pass
+        const int g = lane >> cshift;
+        const int c = min(lane & ((1 << cshift) - 1), pitch - 1);
+        const bool col_ok = (lane & ((1 << cshift) - 1)) < pitch;
+        const uint8_t* p = base + (size_t)g * ref_stride_raw + 4u * (uint32_t)c;
+        uint32_t* w = win + g * pitch + c;
+        const size_t step = (size_t)G * ref_stride_raw;    // uniform
+        const int wstep = G * pitch;
+        int r = g;
+        for (; r + 7 * G < wrows; r += 8 * G) {            // all 8 rows of this lane exist
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = ldu32_nb(p + (size_t)k * step);
+            if (col_ok) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) w[k * wstep] = v[k];
+            }
+            p += 8 * step;
+            w += 8 * wstep;
+        }
+        {                                                   // tail: rows clamped for the loads, masked for the stores
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int rr = min(r + k * G, wrows - 1) - r;   // >= 0 whenever this lane stores anything
+                v[k] = ldu32_nb(p + (ptrdiff_t)rr * (ptrdiff_t)ref_stride_raw);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (col_ok && r + k * G < wrows) w[k * wstep] = v[k];
+        }
+        return;
+    }
     const int total = wrows * pitch;
     const uint32_t inv_pitch = (1u << 20) / (uint32_t)pitch + 1u;  // i / pitch == (i * inv) >> 20 for i < 2^20 / pitch
     for (int i0 = 0; i0 < total; i0 += 512) {
