@@ -43,7 +43,6 @@ def build_pool(n_pictures, rank_seed):
 
     pics = [synth.PaPicture(synth.synth_luma(W, H, t, seed=synth.SEED + 1000 * rank_seed)) for t in range(n_pictures + 1)]
     pool, pdesc = svtav1_hip.build_picture_pool(pics)
-    pool = np.concatenate([pool, np.zeros(64, np.uint8)])
     descs = []
     for i in range(n_pictures):
         d = svtav1_hip.make_fullpel_desc(pics[i + 1], pics[i], None, SEARCH_W, SEARCH_H).astype(np.int64)
@@ -59,7 +58,7 @@ def cpu_baseline(pool, stride, desc, seconds=12.0):
     cores, one thread per core over disjoint SB ranges; falls back to the repo's C port."""
     from oracle.binding import Oracle, Reference
 
-    pool2d = pool.reshape(-1, stride)
+    pool2d = pool[: (pool.size // stride) * stride].reshape(-1, stride)   # flat pool viewed with the full-plane stride
     # the GPU box gives one GPU job a 16-CPU share; never start more workers than that
     try:
         ncores = len(os.sched_getaffinity(0))
@@ -186,6 +185,16 @@ def main():
     # dominant-kernel duration, HIP events on the stream the kernel runs on
     kern_ms = ctx.fullpel_search_time_dev(*a, max(5, min(args.steps, 20)))
 
+    # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc (counters cannot be read from inside the
+    # process); tools/run_pmc_traffic.sh -> profiles/r01_pmc_traffic.json, KB per launch of this same workload
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)["svthip::fullpel85_kernel"]
+        traffic = round((t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0)
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         total_blocks = n_blocks * world * args.steps
         value = total_blocks / elapsed
@@ -210,7 +219,10 @@ def main():
                        "pictures_per_step_per_gpu": PICTURES_PER_STEP, "blocks_per_step_per_gpu": n_blocks,
                        "search_area": [SEARCH_W, SEARCH_H], "sharding": "pictures across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "traffic_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB x 1024 from a separate rocprofv3 --pmc run "
+                                         "(profiles/r01_pmc_traffic.json); 4-byte-per-lane loads, for which the gfx950 FETCH_SIZE "
+                                         "scale is uncalibrated (x1..x2); algorithmic bytes per launch = 20905 x blocks",
                          "kernel": "fullpel85_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_block": ALGO_BYTES_PER_BLOCK,
                          "note": "search is ~400 abs-diff per compulsory byte: VALU-bound by construction (SURVEY 8d); see valu",
