@@ -16,7 +16,9 @@
 // L,R,T,B,TL,TR,BR,BL evaluation order with strict '<', and the 64x64 PU being quarter-pel refined on a 32x32 block.
 //
 // One 256-thread workgroup per (SB, list); wave 0 refines the 64x64 PU, wave 1 the four 32x32, wave 2 the sixteen
-// 16x16, wave 3 the sixty-four 8x8 (equal pixel area per wave).
+// 16x16, wave 3 the sixty-four 8x8 (equal pixel area per wave).  Small PUs are refined several at a time by lane groups
+// (16 lanes per 16x16 PU -> 4 PUs per pass, 8 lanes per 8x8 PU -> 8 PUs per pass), each group with its own tiles, so a wave
+// pays the LDS round trips and the (group-wide) reductions once per pass instead of once per PU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,6 +30,8 @@ namespace svthip {
 namespace {
 
 constexpr int kMargin = 4;  // integer samples staged around the search region on every side
+constexpr int kGroups16 = 4;  // 16x16 PUs refined per pass (16 lanes each)
+constexpr int kGroups8 = 8;   // 8x8 PUs refined per pass (8 lanes each)
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int f4(int a, int b, int c, int d) { return clip8((-2 * a + 18 * b + 18 * c - 2 * d + 16) >> 5); }
@@ -37,10 +41,76 @@ __device__ __forceinline__ uint32_t wrap_sq(int a, int b)
     const int e = d > 128 ? 256 - d : d;  // |int8(a - b)| with -128 -> 128 (ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c:599-608)
     return (uint32_t)(e * e);
 }
+// ---- four pixels at a time: packed-byte helpers -------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+// 4 bytes at an arbitrary LDS byte address (two aligned dword reads + v_alignbyte; reads up to 7 bytes past p)
+__device__ __forceinline__ uint32_t lds_u32_at(const uint8_t* p)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u));
+}
+// bytewise (a - b) mod 256
+__device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b)
+{
+    return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u);
+}
+// sum over 4 bytes of wrap_sq: e = |int8(s - c)| with -128 -> 128, e * e
+__device__ __forceinline__ uint32_t wssd4(uint32_t s, uint32_t c, uint32_t acc)
+{
+    const uint32_t d = sub_u8x4(s, c);
+    const uint32_t m = (d >> 7) & 0x01010101u;        // 1 in every byte whose difference is negative
+    const uint32_t e = (d ^ ((m << 8) - m)) + m;      // bytewise |d|: (d ^ 0xff) + 1 <= 128 never carries
+    return __builtin_amdgcn_udot4(e, e, acc, false);
+}
+// bytewise (a + b + 1) >> 1
+__device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
+// sum over 4 bytes of (s - v)^2, exact: s.s + v.v - 2 s.v
+__device__ __forceinline__ uint32_t ssd4(uint32_t s, uint32_t v, uint32_t acc)
+{
+    const uint32_t pos = __builtin_amdgcn_udot4(s, s, __builtin_amdgcn_udot4(v, v, acc, false), false);
+    return pos - 2u * __builtin_amdgcn_udot4(s, v, 0u, false);
+}
+// {-2,18,18,-2} + 16 >> 5, clipped, on the 4 bytes of w (one output sample)
+__device__ __forceinline__ uint32_t hfilt1(uint32_t w)
+{
+    const int v = ((int)__builtin_amdgcn_udot4(w, 0x00121200u, 16u, false) - (int)__builtin_amdgcn_udot4(w, 0x02000002u, 0u, false)) >> 5;
+    uint32_t r = (uint32_t)min(max(v, 0), 255);
+    // keep the clipped sample opaque: left to itself the compiler fuses "shift, clip, pack two bytes" of neighbouring samples
+    // into v_ashr_pk_u8_i32, whose result did not match the C semantics here (gfx950, ROCm 7.2: wrong bytes in the tiles)
+    asm volatile("" : "+v"(r));
+    return r;
+}
+// the same filter down 4 rows for the 4 byte columns of r0..r3 (packed 16-bit lanes: even and odd columns)
+__device__ __forceinline__ uint32_t vfilt4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3)
+{
+    const uint32_t M = 0x00ff00ffu;
+    uint32_t out = 0;
+#pragma unroll
+    for (int odd = 0; odd < 2; odd++) {
+        const uint32_t a0 = (r0 >> (8 * odd)) & M, a1 = (r1 >> (8 * odd)) & M, a2 = (r2 >> (8 * odd)) & M, a3 = (r3 >> (8 * odd)) & M;
+        v2s s12 = __builtin_bit_cast(v2s, a1) + __builtin_bit_cast(v2s, a2);
+        v2s s03 = __builtin_bit_cast(v2s, a0) + __builtin_bit_cast(v2s, a3);
+        v2s v = (s12 * (short)18 - s03 * (short)2 + (short)16) >> (short)5;
+        v = __builtin_elementwise_min(__builtin_elementwise_max(v, (v2s)(short)0), (v2s)(short)255);
+        out |= __builtin_bit_cast(uint32_t, v) << (8 * odd);
+    }
+    return out;
+}
+
 __device__ __forceinline__ uint32_t wsum(uint32_t v)
 {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+template <int LPP>
+__device__ __forceinline__ uint32_t gsum(uint32_t v)  // sum over the LPP consecutive lanes of a PU's lane group
+{
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) v += __shfl_xor(v, m);
     return v;
 }
 
@@ -91,49 +161,65 @@ struct Tiles {
     __device__ __forceinline__ int j(int tx, int ty) const { return jt[ty * TW + tx]; }
 };
 
+// tile memory of a workgroup: one 64x64 set, one 32x32 set, kGroups16 16x16 sets, kGroups8 8x8 sets
+constexpr int kPredBytes = 4096 + 1024 + kGroups16 * 256 + kGroups8 * 64;  // list-0 predictions of the bi-pred kernel
+constexpr int kTileBytes = (Tiles<64>::bytes + Tiles<32>::bytes + kGroups16 * Tiles<16>::bytes + kGroups8 * Tiles<8>::bytes + 15) & ~15;
+
 template <int W>
-__device__ __forceinline__ int plane_sample(const Win& win, const Tiles<W>& t, int plane, int x, int y, int bx, int by)
+__device__ __forceinline__ uint32_t plane_sample4(const Win& win, const Tiles<W>& t, int plane, int x, int y, int bx, int by)
 {
-    // (x,y) search-region coordinates; tiles cover [bx-2, bx+W+2) x [by-2, by+W+2)
+    // 4 horizontally consecutive samples starting at search-region (x,y); tiles cover [bx-2, bx+W+2) x [by-2, by+W+2).
+    // One address computation for the four planes: the plane index is uniform within a lane group but may differ between
+    // the groups of a wave.
     const int tx = x - (bx - 2), ty = y - (by - 2);
-    if (plane == 0) return win.at(x, y);
-    if (plane == 1) return t.b(tx, ty);
-    if (plane == 2) return t.h(tx, ty);
-    return t.j(tx, ty);
+    const uint8_t* base = plane == 0 ? win.p : (plane == 1 ? t.bt : (plane == 2 ? t.ht : t.jt));
+    const int pitch = plane == 0 ? win.pitch : Tiles<W>::TW;
+    const int cx = plane == 0 ? x + kMargin : tx;
+    const int cy = plane == 0 ? y + kMargin : (plane == 1 ? ty + 2 : ty);
+    return lds_u32_at(base + cy * pitch + cx);
 }
 
 // Fill the b / h / j tiles of a W x W PU whose full-pel block sits at search-region (bx,by).
-template <int W>
-__device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int lane)
+template <int W, int LPP>
+__device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
 {
-    constexpr int TW = Tiles<W>::TW;
+    constexpr int TW = Tiles<W>::TW, TW4 = TW / 4;  // a lane produces 4 horizontally consecutive samples per step
     const int x0 = bx - 2;
-    for (int i = lane; i < TW * (W + 8); i += 64) {  // b rows by-4 .. by+W+3
-        const int r = i / TW, c = i - r * TW;
-        const int x = x0 + c, y = by - 4 + r;
-        t.bt[i] = (uint8_t)f4(win.at(x - 2, y), win.at(x - 1, y), win.at(x, y), win.at(x + 1, y));
+    for (int i = l; i < TW4 * (W + 8); i += LPP) {  // b rows by-4 .. by+W+3
+        const int r = i / TW4, c = 4 * (i - r * TW4);
+        const uint8_t* p = win.p + (by - 4 + r + kMargin) * win.pitch + (x0 + c - 2 + kMargin);  // 7 input bytes from here
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+        const uint32_t sh = (uint32_t)(a & 3u);
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(q[1], q[0], sh), e1 = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
+        const uint32_t o = hfilt1(e0) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 8) |
+                           (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 2)) << 16) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 3)) << 24);
+        *reinterpret_cast<uint32_t*>(t.bt + r * TW + c) = o;
     }
-    for (int i = lane; i < TW * (W + 4); i += 64) {  // h rows by-2 .. by+W+1
-        const int r = i / TW, c = i - r * TW;
-        const int x = x0 + c, y = by - 2 + r;
-        t.ht[i] = (uint8_t)f4(win.at(x, y - 2), win.at(x, y - 1), win.at(x, y), win.at(x, y + 1));
+#pragma unroll 2
+    for (int i = l; i < TW4 * (W + 4); i += LPP) {  // h rows by-2 .. by+W+1
+        const int r = i / TW4, c = 4 * (i - r * TW4);
+        const uint8_t* p = win.p + (by - 2 + r - 2 + kMargin) * win.pitch + (x0 + c + kMargin);  // rows y-2 .. y+1
+        *reinterpret_cast<uint32_t*>(t.ht + r * TW + c) =
+            vfilt4(lds_u32_at(p), lds_u32_at(p + win.pitch), lds_u32_at(p + 2 * win.pitch), lds_u32_at(p + 3 * win.pitch));
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    for (int i = lane; i < TW * (W + 4); i += 64) {  // j from the rounded b: rows (ty-2 .. ty+1) of b
-        const int r = i / TW, c = i - r * TW;
-        // tile row r <-> b tile row index r (b has 2 extra rows on top): b(ty-2) = bt[(r) * TW], ... b(ty+1) = bt[(r+3) * TW]
-        t.jt[i] = (uint8_t)f4(t.bt[r * TW + c], t.bt[(r + 1) * TW + c], t.bt[(r + 2) * TW + c], t.bt[(r + 3) * TW + c]);
+#pragma unroll 2
+    for (int i = l; i < TW4 * (W + 4); i += LPP) {  // j from the rounded b: tile row r <- b tile rows r .. r+3
+        const int r = i / TW4, c = 4 * (i - r * TW4);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(t.bt + r * TW + c);
+        *reinterpret_cast<uint32_t*>(t.jt + r * TW + c) = vfilt4(q[0], q[TW4], q[2 * TW4], q[3 * TW4]);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// One PU (PW x PW pixels at (px,py) in the SB; tiles sized for TWd >= PW).  Runs on one wave; all lanes return the
-// same (uniform) updated sad / mv / ssd / dir.
-template <int PW, int TWd>
+// One PU (PW x PW pixels at (px,py) in the SB; tiles sized for TWd >= PW) per group of LPP consecutive lanes, l = lane
+// within the group.  All lanes of a group return the same updated sad / mv / ssd / dir.
+template <int PW, int TWd, int LPP>
 __device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by,
-                            int x_mv, int y_mv, int lane, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int& dir)
+                            int x_mv, int y_mv, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int& dir)
 {
     // candidate k: plane, dx, dy  (L, R, T, B, TL, TR, BR, BL)
     uint32_t ssd[9], sad[8];
@@ -141,23 +227,33 @@ __device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>
     for (int k = 0; k < 9; k++) ssd[k] = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) sad[k] = 0;
-    for (int i = lane; i < PW * PW; i += 64) {
-        const int y = i / PW, x = i - y * PW;
-        const int s = src[(py + y) * 64 + px + x];
-        const int tx = x + 2, ty = y + 2;
-        const int c[8] = {t.b(tx, ty), t.b(tx + 1, ty), t.h(tx, ty), t.h(tx, ty + 1),
-                          t.j(tx, ty), t.j(tx + 1, ty), t.j(tx + 1, ty + 1), t.j(tx, ty + 1)};
-        ssd[8] += wrap_sq(s, win.at(bx + x, by + y));
+    constexpr int TW = Tiles<TWd>::TW, PW4 = PW / 4;
+#pragma unroll 1  // a wider unroll makes the compiler hoist every LDS load of the 17 accumulations (256 VGPRs)
+    for (int i = l; i < PW4 * PW; i += LPP) {  // 4 pixels per step
+        const int y = i / PW4, x = 4 * (i - y * PW4);
+        const uint32_t s4 = *reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x);
+        // tile samples of pixel x sit at tile column x + 2: rows are 4-byte aligned, so L / R candidates are the two
+        // aligned dwords at column x shifted by 2 / 3 bytes
+        const uint32_t* bq = reinterpret_cast<const uint32_t*>(t.bt + (y + 4) * TW + x);
+        const uint32_t* hq = reinterpret_cast<const uint32_t*>(t.ht + (y + 2) * TW + x);
+        const uint32_t* jq = reinterpret_cast<const uint32_t*>(t.jt + (y + 2) * TW + x);
+        const uint32_t b0 = bq[0], b1 = bq[1], h0 = hq[0], h1 = hq[1], h2 = hq[TW / 4], h3 = hq[TW / 4 + 1];
+        const uint32_t j0 = jq[0], j1 = jq[1], j2 = jq[TW / 4], j3 = jq[TW / 4 + 1];
+        const uint32_t c[8] = {__builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b1, b0, 3),
+                               __builtin_amdgcn_alignbyte(h1, h0, 2), __builtin_amdgcn_alignbyte(h3, h2, 2),
+                               __builtin_amdgcn_alignbyte(j1, j0, 2), __builtin_amdgcn_alignbyte(j1, j0, 3),
+                               __builtin_amdgcn_alignbyte(j3, j2, 3), __builtin_amdgcn_alignbyte(j3, j2, 2)};
+        ssd[8] = wssd4(s4, lds_u32_at(win.p + (by + y + kMargin) * win.pitch + bx + x + kMargin), ssd[8]);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            ssd[k] += wrap_sq(s, c[k]);
-            sad[k] += (uint32_t)abs(s - c[k]);
+            ssd[k] = wssd4(s4, c[k], ssd[k]);
+            sad[k] = __builtin_amdgcn_sad_u8(s4, c[k], sad[k]);
         }
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) ssd[k] = wsum(ssd[k]);
+    for (int k = 0; k < 9; k++) ssd[k] = gsum<LPP>(ssd[k]);
 #pragma unroll
-    for (int k = 0; k < 8; k++) sad[k] = wsum(sad[k]);
+    for (int k = 0; k < 8; k++) sad[k] = gsum<LPP>(sad[k]);
     best_ssd = ssd[8];  // SSD of the best full-pel candidate (:1912)
     const int mvdx[8] = {-2, 2, 0, 0, -2, 2, 2, -2}, mvdy[8] = {0, 0, -2, 2, -2, -2, 2, 2};
 #pragma unroll
@@ -176,9 +272,9 @@ __device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>
         : (m == ssd[4]) ? DIR_TL : (m == ssd[5]) ? DIR_TR : (m == ssd[7]) ? DIR_BL : DIR_BR;
 }
 
-template <int PW, int TWd>
+template <int PW, int TWd, int LPP>
 __device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by, int xo,
-                               int yo, int lane, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int d)
+                               int yo, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int d)
 {
     const int x_mv = (int)(int16_t)(best_mv & 0xffffu), y_mv = (int)(int16_t)(best_mv >> 16);
     const int xs = ((x_mv + 2) >> 2) - xo + px, ys = ((y_mv + 2) >> 2) - yo + py;  // :2847-2848 (+ PU offset)
@@ -204,24 +300,28 @@ __device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<T
         valid[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
     }
     const int qdx[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, qdy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+#pragma unroll
     for (int k = 0; k < 8; k++) {
-        if (!valid[k]) continue;  // wave-uniform
+        // a candidate is evaluated when any lane group of the wave needs it (<= 3 per group); groups that do not need it
+        // compute it too but ignore the result, which keeps the wave convergent for the group reductions
+        if (__ballot(valid[k]) == 0) continue;
         const int q1 = kQuarter[method][k][0], q2 = kQuarter[method][k][1];
         const int p1 = q1 & 3, dx1 = ((q1 >> 2) & 3) - 1, dy1 = ((q1 >> 4) & 3) - 1;
         const int p2 = q2 & 3, dx2 = ((q2 >> 2) & 3) - 1, dy2 = ((q2 >> 4) & 3) - 1;
         uint32_t ssd = 0, sad = 0;
-        for (int i = lane; i < PW * PW; i += 64) {
-            const int y = i / PW, x = i - y * PW;
-            const int s = src[(py + y) * 64 + px + x];
-            const int a = plane_sample<TWd>(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
-            const int b = plane_sample<TWd>(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
-            const int e = s - ((a + b + 1) >> 1);
-            ssd += (uint32_t)(e * e);  // CombinedAveragingSSD: true SSD (:2792-2817)
-            sad += (uint32_t)abs(e);
+#pragma unroll 2
+        for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
+            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
+            const uint32_t s4 = *reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x);
+            const uint32_t a = plane_sample4<TWd>(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
+            const uint32_t b = plane_sample4<TWd>(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
+            const uint32_t v = avg_u8x4(a, b);
+            ssd = ssd4(s4, v, ssd);  // CombinedAveragingSSD: true SSD (:2792-2817)
+            sad = __builtin_amdgcn_sad_u8(s4, v, sad);
         }
-        ssd = wsum(ssd);
-        sad = wsum(sad);
-        if (ssd < best_ssd) {
+        ssd = gsum<LPP>(ssd);
+        sad = gsum<LPP>(sad);
+        if (valid[k] && ssd < best_ssd) {
             best_sad = sad;
             best_mv = ((uint32_t)(uint16_t)(y_mv + qdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + qdx[k]);
             best_ssd = ssd;
@@ -229,22 +329,22 @@ __device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<T
     }
 }
 
-// half + quarter for one PU of size PW at (px,py); `pu` = ME-buffer index
-template <int PW>
-__device__ void refine_pu(const uint8_t* src, const Win& win, Tiles<PW>& t, int px, int py, int xo, int yo, int lane,
+// half + quarter for one PU of size PW at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
+template <int PW, int LPP>
+__device__ void refine_pu(const uint8_t* src, const Win& win, Tiles<PW>& t, int px, int py, int xo, int yo, int l,
                           uint32_t* sad_io, uint32_t* mv_io, int pu)
 {
     uint32_t bs = sad_io[pu], bm = mv_io[pu], bssd = 0;
     const int x_mv = (int)(int16_t)(bm & 0xffffu), y_mv = (int)(int16_t)(bm >> 16);
     const int bx = (x_mv >> 2) - xo + px, by = (y_mv >> 2) - yo + py;
-    fill_tiles<PW>(win, t, bx, by, lane);
+    fill_tiles<PW, LPP>(win, t, bx, by, l);
     int dir = 0;
-    half_pel_pu<PW, PW>(src, win, t, px, py, bx, by, x_mv, y_mv, lane, bs, bm, bssd, dir);
+    half_pel_pu<PW, PW, LPP>(src, win, t, px, py, bx, by, x_mv, y_mv, l, bs, bm, bssd, dir);
     if (PW == 64)  // the 64x64 PU is quarter-pel refined on a 32x32 block at the SB origin (:3395-3409)
-        quarter_pel_pu<32, PW>(src, win, t, px, py, bx, by, xo, yo, lane, bs, bm, bssd, dir);
+        quarter_pel_pu<32, PW, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
     else
-        quarter_pel_pu<PW, PW>(src, win, t, px, py, bx, by, xo, yo, lane, bs, bm, bssd, dir);
-    if (lane == 0) {
+        quarter_pel_pu<PW, PW, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
+    if (l == 0) {
         sad_io[pu] = bs;
         mv_io[pu] = bm;
     }
@@ -267,7 +367,7 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     uint8_t* src_lds = smem;
     uint8_t* tile_base = smem + 4096;
     constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
-    uint8_t* wbuf = tile_base + ((t64 + t32 + t16 + t8 + 15) & ~15);
+    uint8_t* wbuf = tile_base + kTileBytes;
     const int wcols = sw + 63 + 2 * kMargin;
     const int wrows = sh + 63 + 2 * kMargin;
     const int pitch = (wcols + 3) & ~3;
@@ -300,21 +400,25 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
 
     if (wave == 0) {
         Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-        refine_pu<64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
+        refine_pu<64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
     } else if (wave == 1) {
         uint8_t* b = tile_base + t64;
         Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
-        for (int p = 0; p < 4; p++) refine_pu<32>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
+        for (int p = 0; p < 4; p++) refine_pu<32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
     } else if (wave == 2) {
-        uint8_t* b = tile_base + t64 + t32;
+        uint8_t* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
         Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
-        for (int p = 0; p < 16; p++)
-            refine_pu<16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane, sad_io, mv_io, 5 + kTab16[p]);
+        for (int pass = 0; pass < 4; pass++) {
+            const int p = pass * 4 + (lane >> 4);
+            refine_pu<16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p]);
+        }
     } else if (!disable_8x8) {
-        uint8_t* b = tile_base + t64 + t32 + t16;
+        uint8_t* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
         Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
-        for (int p = 0; p < 64; p++)
-            refine_pu<8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane, sad_io, mv_io, 21 + kTab8[p]);
+        for (int pass = 0; pass < 8; pass++) {
+            const int p = pass * 8 + (lane >> 3);
+            refine_pu<8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p]);
+        }
     }
 }
 
@@ -326,61 +430,60 @@ namespace {
 // prediction sample of one list at fractional position frac = (x_mv & 3) + ((y_mv & 3) << 2); (x,y) = integer position
 // in search-region coordinates.  F = A(x,y), Bq = b(x+1,y), Hq = h(x,y+1), Jq = j(x+1,y+1) are the samples
 // BiPredictionCompensation's buffer indices select (:5155-5158); quarter positions average two of them
-// (QuarterPelCompensation :4844-4910).
+// (QuarterPelCompensation :4844-4910).  Table: two (plane, dx, dy) samples per frac, averaged with rounding; the pure
+// positions list the same sample twice (avg(a, a) = a), so one code path serves every lane group of a wave.
+#define BS(p, dx, dy) ((p) | ((dx) << 2) | ((dy) << 3))
+__device__ const uint8_t kBiFrac[16][2] = {
+    {BS(0, 0, 0), BS(0, 0, 0)}, {BS(0, 0, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(0, 1, 0)},
+    {BS(0, 0, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(3, 1, 1)}, {BS(1, 1, 0), BS(2, 1, 1)},
+    {BS(2, 0, 1), BS(2, 0, 1)}, {BS(2, 0, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(2, 1, 1)},
+    {BS(2, 0, 1), BS(0, 0, 1)}, {BS(2, 0, 1), BS(1, 1, 1)}, {BS(3, 1, 1), BS(1, 1, 1)}, {BS(2, 1, 1), BS(1, 1, 1)}};
+#undef BS
+
 template <int TWd>
-__device__ __forceinline__ int bipred_sample(const Win& win, const Tiles<TWd>& t, int frac, int x, int y, int bx, int by)
+__device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const Tiles<TWd>& t, int e0, int e1, int x, int y, int bx, int by)
 {
-    const int tx = x - (bx - 2), ty = y - (by - 2);
-#define AV(a, b) (((a) + (b) + 1) >> 1)
-    switch (frac) {
-    case 0: return win.at(x, y);
-    case 2: return t.b(tx + 1, ty);
-    case 8: return t.h(tx, ty + 1);
-    case 10: return t.j(tx + 1, ty + 1);
-    case 1: return AV(win.at(x, y), t.b(tx + 1, ty));
-    case 3: return AV(t.b(tx + 1, ty), win.at(x + 1, y));
-    case 4: return AV(win.at(x, y), t.h(tx, ty + 1));
-    case 5: return AV(t.b(tx + 1, ty), t.h(tx, ty + 1));
-    case 6: return AV(t.b(tx + 1, ty), t.j(tx + 1, ty + 1));
-    case 7: return AV(t.b(tx + 1, ty), t.h(tx + 1, ty + 1));
-    case 9: return AV(t.h(tx, ty + 1), t.j(tx + 1, ty + 1));
-    case 11: return AV(t.j(tx + 1, ty + 1), t.h(tx + 1, ty + 1));
-    case 12: return AV(t.h(tx, ty + 1), win.at(x, y + 1));
-    case 13: return AV(t.h(tx, ty + 1), t.b(tx + 1, ty + 1));
-    case 14: return AV(t.j(tx + 1, ty + 1), t.b(tx + 1, ty + 1));
-    default: return AV(t.h(tx + 1, ty + 1), t.b(tx + 1, ty + 1));
-    }
-#undef AV
+    const uint32_t a = plane_sample4<TWd>(win, t, e0 & 3, x + ((e0 >> 2) & 1), y + ((e0 >> 3) & 1), bx, by);
+    const uint32_t b = plane_sample4<TWd>(win, t, e1 & 3, x + ((e1 >> 2) & 1), y + ((e1 >> 3) & 1), bx, by);
+    return avg_u8x4(a, b);
 }
 
-// bi-pred SAD of one PU by one wave: list-0 prediction goes through `pred0` (PW*PW bytes of LDS) so the tile
-// memory can be reused for list 1
-template <int PW>
+// bi-pred SAD of one PU per group of LPP lanes: list-0 prediction goes through `pred0` (PW*PW bytes of LDS per group) so the
+// tile memory can be reused for list 1
+template <int PW, int LPP>
 __device__ uint32_t bipred_pu(const uint8_t* src, const Win& win0, const Win& win1, Tiles<PW>& t, uint8_t* pred0, int px, int py,
-                              uint32_t mv0, int xo0, int yo0, uint32_t mv1, int xo1, int yo1, int lane)
+                              uint32_t mv0, int xo0, int yo0, uint32_t mv1, int xo1, int yo1, int l)
 {
     const int x0 = (int)(int16_t)(mv0 & 0xffffu), y0 = (int)(int16_t)(mv0 >> 16);
     const int x1 = (int)(int16_t)(mv1 & 0xffffu), y1 = (int)(int16_t)(mv1 >> 16);
     const int f0 = (x0 & 3) + ((y0 & 3) << 2), f1 = (x1 & 3) + ((y1 & 3) << 2);
     const int bx0 = (x0 >> 2) - xo0 + px, by0 = (y0 >> 2) - yo0 + py;
     const int bx1 = (x1 >> 2) - xo1 + px, by1 = (y1 >> 2) - yo1 + py;
-    if (f0) fill_tiles<PW>(win0, t, bx0, by0, lane);
-    for (int i = lane; i < PW * PW; i += 64) {
-        const int y = i / PW, x = i - y * PW;
-        pred0[i] = (uint8_t)bipred_sample<PW>(win0, t, f0, bx0 + x, by0 + y, bx0, by0);
+    if (__ballot(f0 != 0)) fill_tiles<PW, LPP>(win0, t, bx0, by0, l);  // integer positions read only the window
+    {
+        const int e0 = kBiFrac[f0][0], e1 = kBiFrac[f0][1];
+#pragma unroll 2
+        for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
+            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
+            reinterpret_cast<uint32_t*>(pred0)[i] = bipred_sample4<PW>(win0, t, e0, e1, bx0 + x, by0 + y, bx0, by0);
+        }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (f1) fill_tiles<PW>(win1, t, bx1, by1, lane);
+    if (__ballot(f1 != 0)) fill_tiles<PW, LPP>(win1, t, bx1, by1, l);
     uint32_t sad = 0;
-    for (int i = lane; i < PW * PW; i += 64) {
-        const int y = i / PW, x = i - y * PW;
-        const int p1 = bipred_sample<PW>(win1, t, f1, bx1 + x, by1 + y, bx1, by1);
-        const int avg = ((int)pred0[i] + p1 + 1) >> 1;
-        sad += (uint32_t)abs((int)src[(py + y) * 64 + px + x] - avg);
+    {
+        const int e0 = kBiFrac[f1][0], e1 = kBiFrac[f1][1];
+#pragma unroll 2
+        for (int i = l; i < (PW / 4) * PW; i += LPP) {
+            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
+            const uint32_t p1 = bipred_sample4<PW>(win1, t, e0, e1, bx1 + x, by1 + y, bx1, by1);
+            const uint32_t avg = avg_u8x4(reinterpret_cast<const uint32_t*>(pred0)[i], p1);
+            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x), avg, sad);
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    return wsum(sad);
+    return gsum<LPP>(sad);
 }
 
 __device__ void stage_window(uint8_t* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid)
@@ -423,12 +526,12 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
     if (n_lists == 2) {
         const int32_t* d0 = desc0 + 6 * sb;
         const int32_t* d1 = desc1 + 6 * sb;
-        // LDS: [src 4096][pred0 64|32|16|8][tiles 64|32|16|8][window 0][window 1]
+        // LDS: [src 4096][pred0 64 | 32 | 4 x 16 | 8 x 8][tiles 64 | 32 | 4 x 16 | 8 x 8][window 0][window 1]
         uint8_t* src_lds = smem;
         uint8_t* pred_base = smem + 4096;
-        uint8_t* tile_base = pred_base + 4096 + 1024 + 256 + 64;
+        uint8_t* tile_base = pred_base + kPredBytes;
         constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
-        uint8_t* w0buf = tile_base + ((t64 + t32 + t16 + t8 + 15) & ~15);
+        uint8_t* w0buf = tile_base + kTileBytes;
         uint8_t* w1buf = w0buf + win_bytes;
         const int pitch0 = (d0[4] + 63 + 2 * kMargin + 3) & ~3, pitch1 = (d1[4] + 63 + 2 * kMargin + 3) & ~3;
         for (int i = tid; i < 64 * 16; i += 256) {
@@ -443,33 +546,37 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
         const int xo0 = d0[2], yo0 = d0[3], xo1 = d1[2], yo1 = d1[3];
         if (wave == 0) {
             Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-            const uint32_t v = bipred_pu<64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
+            const uint32_t v = bipred_pu<64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
             if (lane == 0) bisad[0] = v;
         } else if (wave == 1) {
             uint8_t* b = tile_base + t64;
             Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
             for (int p = 0; p < 4; p++) {
-                const uint32_t v = bipred_pu<32>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p], xo0,
-                                                 yo0, m1[1 + p], xo1, yo1, lane);
+                const uint32_t v = bipred_pu<32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p],
+                                                     xo0, yo0, m1[1 + p], xo1, yo1, lane);
                 if (lane == 0) bisad[1 + p] = v;
             }
         } else if (wave == 2) {
-            uint8_t* b = tile_base + t64 + t32;
+            const int g = lane >> 4;  // 4 PUs per pass, 16 lanes each
+            uint8_t* b = tile_base + t64 + t32 + g * t16;
             Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
-            for (int p = 0; p < 16; p++) {
+            for (int pass = 0; pass < 4; pass++) {
+                const int p = pass * 4 + g;
                 const int n = 5 + kTab16[p];
-                const uint32_t v = bipred_pu<16>(src_lds, win0, win1, t, pred_base + 4096 + 1024, (p & 3) << 4, (p >> 2) << 4, m0[n],
-                                                 xo0, yo0, m1[n], xo1, yo1, lane);
-                if (lane == 0) bisad[n] = v;
+                const uint32_t v = bipred_pu<16, 16>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + g * 256, (p & 3) << 4, (p >> 2) << 4,
+                                                     m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 15);
+                if ((lane & 15) == 0) bisad[n] = v;
             }
         } else if (bipred_8x8) {
-            uint8_t* b = tile_base + t64 + t32 + t16;
+            const int g = lane >> 3;  // 8 PUs per pass, 8 lanes each
+            uint8_t* b = tile_base + t64 + t32 + kGroups16 * t16 + g * t8;
             Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
-            for (int p = 0; p < 64; p++) {
+            for (int pass = 0; pass < 8; pass++) {
+                const int p = pass * 8 + g;
                 const int n = 21 + kTab8[p];
-                const uint32_t v = bipred_pu<8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + 256, (p & 7) << 3, (p >> 3) << 3,
-                                                m0[n], xo0, yo0, m1[n], xo1, yo1, lane);
-                if (lane == 0) bisad[n] = v;
+                const uint32_t v = bipred_pu<8, 8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + kGroups16 * 256 + g * 64, (p & 7) << 3,
+                                                   (p >> 3) << 3, m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 7);
+                if ((lane & 7) == 0) bisad[n] = v;
             }
         }
         __syncthreads();
@@ -519,15 +626,13 @@ size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh)
 
 size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
-    const size_t tiles = (Tiles<64>::bytes + Tiles<32>::bytes + Tiles<16>::bytes + Tiles<8>::bytes + 15) & ~(size_t)15;
-    return 4096 + (4096 + 1024 + 256 + 64) + tiles + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
+    return 4096 + kPredBytes + kTileBytes + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
 }
 
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
-    const size_t tiles = (Tiles<64>::bytes + Tiles<32>::bytes + Tiles<16>::bytes + Tiles<8>::bytes + 15) & ~(size_t)15;
     const size_t pitch = (max_sw + 63 + 2 * kMargin + 3) & ~(size_t)3;
-    return 4096 + tiles + pitch * (max_sh + 63 + 2 * kMargin) + 16;
+    return 4096 + kTileBytes + pitch * (max_sh + 63 + 2 * kMargin) + 16;
 }
 
 }  // namespace svthip
