@@ -43,13 +43,16 @@ __device__ __forceinline__ uint32_t wrap_sq(int a, int b)
 }
 // ---- four pixels at a time: packed-byte helpers -------------------------------------------------------------------
 typedef short v2s __attribute__((ext_vector_type(2)));
+// LDS pointers carry their address space: through generic pointers every tile / window read became a flat_load
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // 4 bytes at an arbitrary LDS byte address (two aligned dword reads + v_alignbyte; reads up to 7 bytes past p)
-__device__ __forceinline__ uint32_t lds_u32_at(const uint8_t* p)
+__device__ __forceinline__ uint32_t lds_u32_at(const lds_u8* p)
 {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u));
+    const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);
+    const lds_u32* q = reinterpret_cast<const lds_u32*>((uintptr_t)(a & ~3u));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
 }
 // bytewise (a - b) mod 256
 __device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b)
@@ -142,7 +145,7 @@ __device__ const uint8_t kTab8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,
                                       50, 51, 54, 55, 40, 41, 44, 45, 56, 57, 60, 61, 42, 43, 46, 47, 58, 59, 62, 63};
 
 struct Win {
-    const uint8_t* p;  // LDS window; search-region coordinate (x,y) lives at p[(y + kMargin) * pitch + x + kMargin]
+    const lds_u8* p;  // LDS window; search-region coordinate (x,y) lives at p[(y + kMargin) * pitch + x + kMargin]
     int pitch;
     __device__ __forceinline__ int at(int x, int y) const { return p[(y + kMargin) * pitch + x + kMargin]; }
 };
@@ -152,9 +155,9 @@ struct Win {
 template <int W>
 struct Tiles {
     static constexpr int TW = W + 4;
-    uint8_t* bt;  // [W + 8][TW]
-    uint8_t* ht;  // [W + 4][TW]
-    uint8_t* jt;  // [W + 4][TW]
+    lds_u8* bt;  // [W + 8][TW]
+    lds_u8* ht;  // [W + 4][TW]
+    lds_u8* jt;  // [W + 4][TW]
     static constexpr int bytes = TW * (W + 8) + 2 * TW * (W + 4);
     __device__ __forceinline__ int b(int tx, int ty) const { return bt[(ty + 2) * TW + tx]; }
     __device__ __forceinline__ int h(int tx, int ty) const { return ht[ty * TW + tx]; }
@@ -172,7 +175,7 @@ __device__ __forceinline__ uint32_t plane_sample4(const Win& win, const Tiles<W>
     // One address computation for the four planes: the plane index is uniform within a lane group but may differ between
     // the groups of a wave.
     const int tx = x - (bx - 2), ty = y - (by - 2);
-    const uint8_t* base = plane == 0 ? win.p : (plane == 1 ? t.bt : (plane == 2 ? t.ht : t.jt));
+    const lds_u8* base = plane == 0 ? win.p : (plane == 1 ? (const lds_u8*)t.bt : (plane == 2 ? (const lds_u8*)t.ht : (const lds_u8*)t.jt));
     const int pitch = plane == 0 ? win.pitch : Tiles<W>::TW;
     const int cx = plane == 0 ? x + kMargin : tx;
     const int cy = plane == 0 ? y + kMargin : (plane == 1 ? ty + 2 : ty);
@@ -187,20 +190,20 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
     const int x0 = bx - 2;
     for (int i = l; i < TW4 * (W + 8); i += LPP) {  // b rows by-4 .. by+W+3
         const int r = i / TW4, c = 4 * (i - r * TW4);
-        const uint8_t* p = win.p + (by - 4 + r + kMargin) * win.pitch + (x0 + c - 2 + kMargin);  // 7 input bytes from here
-        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(a & 3u);
+        const lds_u8* p = win.p + (by - 4 + r + kMargin) * win.pitch + (x0 + c - 2 + kMargin);  // 7 input bytes from here
+        const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);
+        const lds_u32* q = reinterpret_cast<const lds_u32*>((uintptr_t)(a & ~3u));
+        const uint32_t sh = a & 3u;
         const uint32_t e0 = __builtin_amdgcn_alignbyte(q[1], q[0], sh), e1 = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
         const uint32_t o = hfilt1(e0) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 8) |
                            (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 2)) << 16) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 3)) << 24);
-        *reinterpret_cast<uint32_t*>(t.bt + r * TW + c) = o;
+        *reinterpret_cast<lds_u32*>(t.bt + r * TW + c) = o;
     }
 #pragma unroll 2
     for (int i = l; i < TW4 * (W + 4); i += LPP) {  // h rows by-2 .. by+W+1
         const int r = i / TW4, c = 4 * (i - r * TW4);
-        const uint8_t* p = win.p + (by - 2 + r - 2 + kMargin) * win.pitch + (x0 + c + kMargin);  // rows y-2 .. y+1
-        *reinterpret_cast<uint32_t*>(t.ht + r * TW + c) =
+        const lds_u8* p = win.p + (by - 2 + r - 2 + kMargin) * win.pitch + (x0 + c + kMargin);  // rows y-2 .. y+1
+        *reinterpret_cast<lds_u32*>(t.ht + r * TW + c) =
             vfilt4(lds_u32_at(p), lds_u32_at(p + win.pitch), lds_u32_at(p + 2 * win.pitch), lds_u32_at(p + 3 * win.pitch));
     }
     __builtin_amdgcn_wave_barrier();
@@ -208,8 +211,8 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
 #pragma unroll 2
     for (int i = l; i < TW4 * (W + 4); i += LPP) {  // j from the rounded b: tile row r <- b tile rows r .. r+3
         const int r = i / TW4, c = 4 * (i - r * TW4);
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(t.bt + r * TW + c);
-        *reinterpret_cast<uint32_t*>(t.jt + r * TW + c) = vfilt4(q[0], q[TW4], q[2 * TW4], q[3 * TW4]);
+        const lds_u32* q = reinterpret_cast<const lds_u32*>(t.bt + r * TW + c);
+        *reinterpret_cast<lds_u32*>(t.jt + r * TW + c) = vfilt4(q[0], q[TW4], q[2 * TW4], q[3 * TW4]);
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -218,7 +221,7 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
 // One PU (PW x PW pixels at (px,py) in the SB; tiles sized for TWd >= PW) per group of LPP consecutive lanes, l = lane
 // within the group.  All lanes of a group return the same updated sad / mv / ssd / dir.
 template <int PW, int TWd, int LPP>
-__device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by,
+__device__ void half_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by,
                             int x_mv, int y_mv, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int& dir)
 {
     // candidate k: plane, dx, dy  (L, R, T, B, TL, TR, BR, BL)
@@ -231,12 +234,12 @@ __device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>
 #pragma unroll 1  // a wider unroll makes the compiler hoist every LDS load of the 17 accumulations (256 VGPRs)
     for (int i = l; i < PW4 * PW; i += LPP) {  // 4 pixels per step
         const int y = i / PW4, x = 4 * (i - y * PW4);
-        const uint32_t s4 = *reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x);
+        const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
         // tile samples of pixel x sit at tile column x + 2: rows are 4-byte aligned, so L / R candidates are the two
         // aligned dwords at column x shifted by 2 / 3 bytes
-        const uint32_t* bq = reinterpret_cast<const uint32_t*>(t.bt + (y + 4) * TW + x);
-        const uint32_t* hq = reinterpret_cast<const uint32_t*>(t.ht + (y + 2) * TW + x);
-        const uint32_t* jq = reinterpret_cast<const uint32_t*>(t.jt + (y + 2) * TW + x);
+        const lds_u32* bq = reinterpret_cast<const lds_u32*>(t.bt + (y + 4) * TW + x);
+        const lds_u32* hq = reinterpret_cast<const lds_u32*>(t.ht + (y + 2) * TW + x);
+        const lds_u32* jq = reinterpret_cast<const lds_u32*>(t.jt + (y + 2) * TW + x);
         const uint32_t b0 = bq[0], b1 = bq[1], h0 = hq[0], h1 = hq[1], h2 = hq[TW / 4], h3 = hq[TW / 4 + 1];
         const uint32_t j0 = jq[0], j1 = jq[1], j2 = jq[TW / 4], j3 = jq[TW / 4 + 1];
         const uint32_t c[8] = {__builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b1, b0, 3),
@@ -273,7 +276,7 @@ __device__ void half_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>
 }
 
 template <int PW, int TWd, int LPP>
-__device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by, int xo,
+__device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by, int xo,
                                int yo, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int d)
 {
     const int x_mv = (int)(int16_t)(best_mv & 0xffffu), y_mv = (int)(int16_t)(best_mv >> 16);
@@ -312,7 +315,7 @@ __device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<T
 #pragma unroll 2
         for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            const uint32_t s4 = *reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x);
+            const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
             const uint32_t a = plane_sample4<TWd>(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
             const uint32_t b = plane_sample4<TWd>(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
             const uint32_t v = avg_u8x4(a, b);
@@ -331,7 +334,7 @@ __device__ void quarter_pel_pu(const uint8_t* src, const Win& win, const Tiles<T
 
 // half + quarter for one PU of size PW at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
 template <int PW, int LPP>
-__device__ void refine_pu(const uint8_t* src, const Win& win, Tiles<PW>& t, int px, int py, int xo, int yo, int l,
+__device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW>& t, int px, int py, int xo, int yo, int l,
                           uint32_t* sad_io, uint32_t* mv_io, int pu)
 {
     uint32_t bs = sad_io[pu], bm = mv_io[pu], bssd = 0;
@@ -364,10 +367,10 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
 
     // LDS: [src 64x64][tiles 64 | 32 | 16 | 8][window]
-    uint8_t* src_lds = smem;
-    uint8_t* tile_base = smem + 4096;
+    lds_u8* src_lds = (lds_u8*)smem;
+    lds_u8* tile_base = src_lds + 4096;
     constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
-    uint8_t* wbuf = tile_base + kTileBytes;
+    lds_u8* wbuf = tile_base + kTileBytes;
     const int wcols = sw + 63 + 2 * kMargin;
     const int wrows = sh + 63 + 2 * kMargin;
     const int pitch = (wcols + 3) & ~3;
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     // stage the source SB and the integer window (search position (0,0) at [kMargin][kMargin])
     for (int i = tid; i < 64 * 16; i += 256) {
         const int r = i >> 4, c = i & 15;
-        reinterpret_cast<uint32_t*>(src_lds)[i] =
+        reinterpret_cast<lds_u32*>(src_lds)[i] =
             *reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)r * src_stride + 4 * c);
     }
     {
@@ -389,7 +392,7 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
         for (int i = tid; i < total; i += 256) {
             const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
             const uint32_t* p = base4 + (size_t)r * rstride4 + c;
-            reinterpret_cast<uint32_t*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
+            reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
         }
     }
     __syncthreads();
@@ -402,18 +405,18 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
         Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
         refine_pu<64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
     } else if (wave == 1) {
-        uint8_t* b = tile_base + t64;
+        lds_u8* b = tile_base + t64;
         Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
         for (int p = 0; p < 4; p++) refine_pu<32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
     } else if (wave == 2) {
-        uint8_t* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
+        lds_u8* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
         Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
         for (int pass = 0; pass < 4; pass++) {
             const int p = pass * 4 + (lane >> 4);
             refine_pu<16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p]);
         }
     } else if (!disable_8x8) {
-        uint8_t* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
+        lds_u8* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
         Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
         for (int pass = 0; pass < 8; pass++) {
             const int p = pass * 8 + (lane >> 3);
@@ -451,7 +454,7 @@ __device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const Tiles<T
 // bi-pred SAD of one PU per group of LPP lanes: list-0 prediction goes through `pred0` (PW*PW bytes of LDS per group) so the
 // tile memory can be reused for list 1
 template <int PW, int LPP>
-__device__ uint32_t bipred_pu(const uint8_t* src, const Win& win0, const Win& win1, Tiles<PW>& t, uint8_t* pred0, int px, int py,
+__device__ uint32_t bipred_pu(const lds_u8* src, const Win& win0, const Win& win1, Tiles<PW>& t, lds_u8* pred0, int px, int py,
                               uint32_t mv0, int xo0, int yo0, uint32_t mv1, int xo1, int yo1, int l)
 {
     const int x0 = (int)(int16_t)(mv0 & 0xffffu), y0 = (int)(int16_t)(mv0 >> 16);
@@ -465,7 +468,7 @@ __device__ uint32_t bipred_pu(const uint8_t* src, const Win& win0, const Win& wi
 #pragma unroll 2
         for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            reinterpret_cast<uint32_t*>(pred0)[i] = bipred_sample4<PW>(win0, t, e0, e1, bx0 + x, by0 + y, bx0, by0);
+            reinterpret_cast<lds_u32*>(pred0)[i] = bipred_sample4<PW>(win0, t, e0, e1, bx0 + x, by0 + y, bx0, by0);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -478,15 +481,15 @@ __device__ uint32_t bipred_pu(const uint8_t* src, const Win& win0, const Win& wi
         for (int i = l; i < (PW / 4) * PW; i += LPP) {
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
             const uint32_t p1 = bipred_sample4<PW>(win1, t, e0, e1, bx1 + x, by1 + y, bx1, by1);
-            const uint32_t avg = avg_u8x4(reinterpret_cast<const uint32_t*>(pred0)[i], p1);
-            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t*>(src + (py + y) * 64 + px + x), avg, sad);
+            const uint32_t avg = avg_u8x4(reinterpret_cast<const lds_u32*>(pred0)[i], p1);
+            sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x), avg, sad);
         }
     }
     __builtin_amdgcn_wave_barrier();
     return gsum<LPP>(sad);
 }
 
-__device__ void stage_window(uint8_t* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid)
+__device__ void stage_window(lds_u8* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid)
 {
     const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
@@ -498,7 +501,7 @@ __device__ void stage_window(uint8_t* wbuf, int pitch, int wrows, const uint8_t*
     for (int i = tid; i < total; i += 256) {
         const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
         const uint32_t* p = base4 + (size_t)r * rstride4 + c;
-        reinterpret_cast<uint32_t*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
+        reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
     }
 }
 
@@ -527,16 +530,16 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
         const int32_t* d0 = desc0 + 6 * sb;
         const int32_t* d1 = desc1 + 6 * sb;
         // LDS: [src 4096][pred0 64 | 32 | 4 x 16 | 8 x 8][tiles 64 | 32 | 4 x 16 | 8 x 8][window 0][window 1]
-        uint8_t* src_lds = smem;
-        uint8_t* pred_base = smem + 4096;
-        uint8_t* tile_base = pred_base + kPredBytes;
+        lds_u8* src_lds = (lds_u8*)smem;
+        lds_u8* pred_base = src_lds + 4096;
+        lds_u8* tile_base = pred_base + kPredBytes;
         constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
-        uint8_t* w0buf = tile_base + kTileBytes;
-        uint8_t* w1buf = w0buf + win_bytes;
+        lds_u8* w0buf = tile_base + kTileBytes;
+        lds_u8* w1buf = w0buf + win_bytes;
         const int pitch0 = (d0[4] + 63 + 2 * kMargin + 3) & ~3, pitch1 = (d1[4] + 63 + 2 * kMargin + 3) & ~3;
         for (int i = tid; i < 64 * 16; i += 256) {
             const int r = i >> 4, c = i & 15;
-            reinterpret_cast<uint32_t*>(src_lds)[i] =
+            reinterpret_cast<lds_u32*>(src_lds)[i] =
                 *reinterpret_cast<const uint32_t*>(src_plane + d0[0] + (size_t)r * src_stride + 4 * c);
         }
         stage_window(w0buf, pitch0, d0[5] + 63 + 2 * kMargin, ref0_plane, d0[1], ref0_stride, tid);
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             const uint32_t v = bipred_pu<64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
             if (lane == 0) bisad[0] = v;
         } else if (wave == 1) {
-            uint8_t* b = tile_base + t64;
+            lds_u8* b = tile_base + t64;
             Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
             for (int p = 0; p < 4; p++) {
                 const uint32_t v = bipred_pu<32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p],
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             }
         } else if (wave == 2) {
             const int g = lane >> 4;  // 4 PUs per pass, 16 lanes each
-            uint8_t* b = tile_base + t64 + t32 + g * t16;
+            lds_u8* b = tile_base + t64 + t32 + g * t16;
             Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
             for (int pass = 0; pass < 4; pass++) {
                 const int p = pass * 4 + g;
@@ -569,7 +572,7 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             }
         } else if (bipred_8x8) {
             const int g = lane >> 3;  // 8 PUs per pass, 8 lanes each
-            uint8_t* b = tile_base + t64 + t32 + kGroups16 * t16 + g * t8;
+            lds_u8* b = tile_base + t64 + t32 + kGroups16 * t16 + g * t8;
             Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
             for (int pass = 0; pass < 8; pass++) {
                 const int p = pass * 8 + g;
