@@ -237,6 +237,15 @@ int32_t svthip_motion_estimate_picture_dev(svthip_ctx *ctx, const uint8_t *d_poo
                                            const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
                                            uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
 
+/* The same for n_jobs pictures of equal geometry and strides in one call (cur / ref0 / ref1: HOST arrays of n_jobs
+ * descriptors, ref1 == NULL for P pictures): seven kernel launches whatever n_jobs is.  Per-SB device arrays hold the jobs
+ * back to back: d_out[(j * n_sb + i) * 85 + pu]; d_list_sad / d_list_mv (optional) are [2][n_jobs * n_sb][85]. */
+int32_t svthip_motion_estimate_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                         const svthip_pa_picture *ref0, const svthip_pa_picture *ref1, uint32_t n_jobs,
+                                         const svthip_me_params *params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                         const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
+                                         uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched quantisation + dequantisation + eob of transform units.
  * Replaces aom_quantize_b / aom_quantize_b_32x32 / aom_quantize_b_64x64 (RTCD, Codec/aom_dsp_rtcd.h:310-331; C bodies

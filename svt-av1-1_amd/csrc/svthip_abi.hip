@@ -368,20 +368,25 @@ int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, 
                                                  d_desc, d_center, d_hme_state, stream);
 }
 
-int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                           const svthip_pa_picture* ref0, const svthip_pa_picture* ref1,
-                                           const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
-                                           const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
-                                           uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                         const svthip_pa_picture* ref0, const svthip_pa_picture* ref1, uint32_t n_jobs,
+                                         const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                         const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
+                                         uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
-    if (n_sb == 0) return SVTHIP_OK;
+    if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
     if (!d_pool || !cur || !ref0 || !params || !d_sb || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    for (uint32_t j = 0; j < n_jobs; j++)  // the per-SB kernels take one stride per plane role
+        if (cur[j].full_stride != cur[0].full_stride || ref0[j].full_stride != ref0[0].full_stride ||
+            (ref1 && ref1[j].full_stride != ref1[0].full_stride))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "all pictures of a batch must share their full-resolution strides%s (job %d)", "", (int)j);
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n_lists = ref1 ? 2u : 1u;
+    const size_t n = (size_t)n_jobs * n_sb;
     // scratch: slot 5 holds  desc[2][n] | sad[2][n][85] | mv[2][n][85] | hme_state[n][25]
-    const size_t desc_b = sizeof(svthip_fullpel_desc) * n_sb, arr_b = sizeof(uint32_t) * 85 * (size_t)n_sb;
-    const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * (size_t)n_sb) + 15) & ~(size_t)15;
+    const size_t desc_b = sizeof(svthip_fullpel_desc) * n, arr_b = sizeof(uint32_t) * 85 * n;
+    const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * n) + 15) & ~(size_t)15;
     int32_t rc;
     if ((rc = ensure_scratch(ctx, 5, 2 * desc_b + 4 * arr_b + state_b + 64))) return rc;
     uint8_t* base = static_cast<uint8_t*>(ctx->scratch[5]);
@@ -390,27 +395,39 @@ int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_poo
     uint32_t* mv[2] = {reinterpret_cast<uint32_t*>(base + 2 * desc_b + 2 * arr_b), reinterpret_cast<uint32_t*>(base + 2 * desc_b + 3 * arr_b)};
     int16_t* state = reinterpret_cast<int16_t*>(base + 2 * desc_b + 4 * arr_b);
     if (d_list_sad && d_list_mv) {  // caller wants the per-list arrays: write them in place
-        sad[0] = d_list_sad; sad[1] = d_list_sad + 85 * (size_t)n_sb;
-        mv[0] = d_list_mv; mv[1] = d_list_mv + 85 * (size_t)n_sb;
+        sad[0] = d_list_sad; sad[1] = d_list_sad + 85 * n;
+        mv[0] = d_list_mv; mv[1] = d_list_mv + 85 * n;
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const uint32_t sw = params->search_area_width < 127 ? params->search_area_width : 127;
     const uint32_t sh = params->search_area_height < 127 ? params->search_area_height : 127;
     const svthip_pa_picture* refs[2] = {ref0, ref1};
+    // seven launches whatever the number of pictures: per list search centres -> full-pel -> sub-pel, then bi-prediction + packing
     for (uint32_t l = 0; l < n_lists; l++) {
-        if ((rc = svthip_me_hme_search_center_dev(ctx, d_pool, cur, refs[l], params, l, d_sb, n_sb, l ? mv[0] : nullptr, 85, desc[l],
-                                                  nullptr, state, s)))
+        if ((rc = svthip_me_hme_search_center_batch_dev(ctx, d_pool, cur, refs[l], n_jobs, params, l, d_sb, n_sb, l ? mv[0] : nullptr, 85,
+                                                        desc[l], nullptr, state, s)))
             return rc;
-        if ((rc = launch_fullpel(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], n_sb, sw, sh, sad[l], mv[l], s)))
+        if ((rc = launch_fullpel(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh, sad[l], mv[l], s)))
             return rc;
         if (use_subpel_flag &&
-            (rc = svthip_me_subpel_refine_dev(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], n_sb, sw, sh,
+            (rc = svthip_me_subpel_refine_dev(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh,
                                               cu8x8_mode == 1, sad[l], mv[l], s)))
             return rc;
     }
     return svthip_me_bipred_pack_dev(ctx, d_pool, cur->full_stride, d_pool, ref0->full_stride, desc[0], n_lists == 2 ? d_pool : nullptr,
-                                     n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, n_sb, sw, sh, sad[0], mv[0],
-                                     n_lists == 2 ? sad[1] : nullptr, n_lists == 2 ? mv[1] : nullptr, n_lists, cu8x8_mode == 0, d_out, s);
+                                     n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, (uint32_t)n, sw, sh, sad[0],
+                                     mv[0], n_lists == 2 ? sad[1] : nullptr, n_lists == 2 ? mv[1] : nullptr, n_lists, cu8x8_mode == 0,
+                                     d_out, s);
+}
+
+int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                           const svthip_pa_picture* ref0, const svthip_pa_picture* ref1,
+                                           const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                           const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
+                                           uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+{
+    return svthip_motion_estimate_batch_dev(ctx, d_pool, cur, ref0, ref1, 1, params, use_subpel_flag, cu8x8_mode, d_sb, n_sb, d_out,
+                                            d_list_sad, d_list_mv, stream);
 }
 
 int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size_t src_plane_bytes, uint32_t src_stride,

@@ -79,6 +79,10 @@ def lib() -> C.CDLL:
     L.svthip_motion_estimate_picture_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p]
+    L.svthip_motion_estimate_batch_dev.restype = C.c_int32
+    L.svthip_motion_estimate_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                   C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]
     L.svthip_me_subpel_refine_dev.restype = C.c_int32
     L.svthip_me_subpel_refine_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -202,6 +206,19 @@ def _motion_estimate_picture_dev(self, d_pool, cur, ref0, ref1, params, d_sb, n_
 
 
 Context.motion_estimate_picture_dev = _motion_estimate_picture_dev
+
+
+def _motion_estimate_batch_dev(self, d_pool, curs, refs0, refs1, params, d_sb, n_sb, d_out, use_subpel=True, cu8x8_mode=0,
+                               d_list_sad=None, d_list_mv=None, stream=None):
+    """Whole-picture ME of len(curs) pictures in one call; refs1=None for P pictures."""
+    n = len(curs)
+    ca, r0 = (PaPictureDesc * n)(*curs), (PaPictureDesc * n)(*refs0)
+    r1 = (PaPictureDesc * n)(*refs1) if refs1 is not None else None
+    _check(lib().svthip_motion_estimate_batch_dev(self._h, d_pool, ca, r0, r1, n, C.byref(params), int(use_subpel), int(cu8x8_mode),
+                                                  d_sb, n_sb, d_out, d_list_sad, d_list_mv, stream))
+
+
+Context.motion_estimate_batch_dev = _motion_estimate_batch_dev
 
 
 Context.hme_search_center_dev = _hme_search_center_dev

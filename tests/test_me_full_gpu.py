@@ -67,3 +67,28 @@ def test_motion_estimate_picture_1080p_b_picture(hip_ctx, oracle):
     for l in per:
         assert np.array_equal(ls[l][sample], per[l][1]) and np.array_equal(lm[l][sample], per[l][2])
     compare_results(res_d[sample], res_o)
+
+
+def test_batched_pictures_equal_single_picture_calls(hip_ctx):
+    """svthip_motion_estimate_batch_dev over several B pictures == one svthip_motion_estimate_picture_dev per picture."""
+    torch = pytest.importorskip("torch")
+    w, h, n_pic = 320, 192, 3
+    frames = [synth.PaPicture(synth.synth_luma(w, h, t)) for t in range(n_pic + 2)]
+    pool, pd = svtav1_hip.build_picture_pool(frames)
+    dev = torch.device("cuda:0")
+    d_pool = torch.from_numpy(pool).to(dev)
+    sb = svtav1_hip.sb_origins(w, h)
+    n = sb.shape[0]
+    d_sb = torch.from_numpy(sb.view(np.int16).copy()).to(dev)
+    P = svtav1_hip.default_me_params(w, h, 3, 1)
+    curs = [pd[i + 1] for i in range(n_pic)]; r0 = [pd[i] for i in range(n_pic)]; r1 = [pd[i + 2] for i in range(n_pic)]
+    d_one = torch.zeros((n_pic * n, 85, 24), dtype=torch.uint8, device=dev)
+    for i in range(n_pic):
+        hip_ctx.motion_estimate_picture_dev(d_pool.data_ptr(), curs[i], r0[i], r1[i], P, d_sb.data_ptr(), n,
+                                            d_one.data_ptr() + i * n * 85 * 24, True, 0)
+    d_bat = torch.full((n_pic * n, 85, 24), 0x77, dtype=torch.uint8, device=dev)
+    hip_ctx.motion_estimate_batch_dev(d_pool.data_ptr(), curs, r0, r1, P, d_sb.data_ptr(), n, d_bat.data_ptr(), True, 0)
+    hip_ctx.synchronize()
+    a = d_one.cpu().numpy().view(svtav1_hip.ME_CU_RESULT_DTYPE); b = d_bat.cpu().numpy().view(svtav1_hip.ME_CU_RESULT_DTYPE)
+    for f in ("totalMeCandidateIndex", "xMvL0", "yMvL0", "xMvL1", "yMvL1", "distortion", "direction"):
+        assert np.array_equal(a[f], b[f]), f
