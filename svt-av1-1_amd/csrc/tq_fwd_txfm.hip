@@ -40,6 +40,8 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
     constexpr int SH0 = kShift[WI][HI][0], SH1 = kShift[WI][HI][1], SH2 = kShift[WI][HI][2];
     constexpr int BITC = kCosCol[WI][HI], BITR = kCosRow[WI][HI];
     constexpr bool RECT2 = (WL - HL == 1) || (HL - WL == 1);
+    // rows of >= 16 coefficients leave through LDS with coalesced stores (measured: +10..15 % at 16x16 .. 64x64, -10 % at 4x4 / 8x8)
+    constexpr bool STAGED_OUT = W >= 16;
     extern __shared__ int32_t lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* tile = lds_all + wave * (G * H * P);
@@ -78,16 +80,44 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
 #pragma unroll
                 for (int c = 0; c < W; c++) x[c] = row[c];
                 txfm1d<W, BITR>(kr, x, y);
-                int32_t* out = coeff + d.out_offset + r * W;
+                if constexpr (STAGED_OUT) {
+                    // the finished row goes back to the same LDS row (only this lane touches it between the two barriers) ...
+                    int32_t* orow = tile + g * (H * P) + r * P;
 #pragma unroll
-                for (int c = 0; c < W; c += 4) {
-                    int32_t v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        v[k] = shift_val<SH2>(y[c + k]);
-                        if constexpr (RECT2) v[k] = rs<12>((int64_t)v[k] * 5793);
+                    for (int c = 0; c < W; c++) {
+                        int32_t v = shift_val<SH2>(y[c]);
+                        if constexpr (RECT2) v = rs<12>((int64_t)v * 5793);
+                        orow[c] = v;
                     }
-                    *reinterpret_cast<int4*>(out + c) = make_int4(v[0], v[1], v[2], v[3]);
+                } else {
+                    int32_t* out = coeff + d.out_offset + r * W;
+#pragma unroll
+                    for (int c = 0; c < W; c += 4) {
+                        int32_t v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            v[k] = shift_val<SH2>(y[c + k]);
+                            if constexpr (RECT2) v[k] = rs<12>((int64_t)v[k] * 5793);
+                        }
+                        *reinterpret_cast<int4*>(out + c) = make_int4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+        if constexpr (STAGED_OUT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ... and the group's coefficients leave with coalesced 16-byte stores (a TU is one contiguous run of W * H int32)
+            constexpr int NQ = W * H / 4;
+#pragma unroll 4
+            for (int i = lane; i < G * NQ; i += 64) {
+                const int g = i / NQ, q = i - g * NQ;
+                const uint32_t tu = grp * G + g;
+                if (tu < n_tu) {
+                    const int r = (4 * q) / W, c = (4 * q) % W;
+                    const int32_t* src = tile + g * (H * P) + r * P + c;
+                    *reinterpret_cast<int4*>(coeff + desc[tu].out_offset + 4 * q) = make_int4(src[0], src[1], src[2], src[3]);
                 }
             }
         }
