@@ -203,10 +203,11 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
                 const int ps = d.pred_stride, rs_ = d.recon_stride;
 #pragma unroll
                 for (int r = 0; r < H; r++) {
-                    int32_t t = rs<4>((int64_t)(kc == 2 ? y[H - 1 - r] : y[r]));
+                    int32_t t = rs<4>((int64_t)y[r]);
                     t = min(max(t, -res_max - 1), res_max);
-                    const int32_t v = (int32_t)p[r * ps] + t;
-                    out[r * rs_] = (uint8_t)min(max(v, 0), 255);
+                    const int rr = flip_row<H>(r, kc);
+                    const int32_t v = (int32_t)p[rr * ps] + t;
+                    out[rr * rs_] = (uint8_t)min(max(v, 0), 255);
                 }
             }
         }

@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
     constexpr int WIN = W > 32 ? 32 : W, HIN = H > 32 ? 32 : H;
     constexpr int SH0 = kInvShift0[WI][HI];
     constexpr bool RECT2 = (WL - HL == 1) || (HL - WL == 1);
+    constexpr bool PACKED_RECON = sizeof(PIX) == 1 && W >= 16;  // 8-bit planes, rows of at least 16 pixels
     extern __shared__ int32_t lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* tile = lds_all + wave * (G * H * P);
@@ -93,15 +94,59 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
 #pragma unroll
                 for (int r = HIN; r < H; r++) x[r] = 0;
                 itxfm1d<H, HIN>(kc, x, y, cl_col);
-                PIX* out = recon + d.recon_offset + c;
-                const int stride = d.recon_stride;
+                if constexpr (PACKED_RECON) {
+                    // residual column back to the tile (same lane, same column); reconstruction follows four pixels per lane
+                    int32_t* ocol = tile + g * (H * P) + c;
 #pragma unroll
-                for (int r = 0; r < H; r++) {
-                    int32_t t = rs<4>((int64_t)(kc == 2 ? y[H - 1 - r] : y[r]));  // ud flip as a per-element select
-                    t = min(max(t, -res_max - 1), res_max);
-                    PIX* p = out + r * stride;
-                    const int32_t v = (int32_t)*p + t;
-                    *p = (PIX)min(max(v, 0), pix_max);
+                    for (int r = 0; r < H; r++) {
+                        const int32_t t = rs<4>((int64_t)y[r]);
+                        ocol[flip_row<H>(r, kc) * P] = min(max(t, -res_max - 1), res_max);
+                    }
+                } else {
+                    PIX* out = recon + d.recon_offset + c;
+                    const int stride = d.recon_stride;
+#pragma unroll
+                    for (int r = 0; r < H; r++) {
+                        int32_t t = rs<4>((int64_t)y[r]);
+                        t = min(max(t, -res_max - 1), res_max);
+                        PIX* p = out + flip_row<H>(r, kc) * stride;
+                        const int32_t v = (int32_t)*p + t;
+                        *p = (PIX)min(max(v, 0), pix_max);
+                    }
+                }
+            }
+        }
+        if constexpr (PACKED_RECON) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // prediction + residual -> clip, 4 horizontally consecutive 8-bit pixels per lane (one dword load / store instead of
+            // four byte loads / stores per lane); TUs whose rows are not 4-byte aligned take the byte path
+            for (int g = 0; g < G; g++) {
+                const uint32_t tu = grp * G + g;  // uniform
+                if (tu >= n_tu) break;
+                const svthip_itxfm_desc d = desc[tu];
+                uint8_t* base = reinterpret_cast<uint8_t*>(recon) + d.recon_offset;
+                const int stride = d.recon_stride;
+                const int32_t* tg = tile + g * (H * P);
+                if ((((uintptr_t)base | (uintptr_t)stride) & 3u) == 0) {
+#pragma unroll 2
+                    for (int q = lane; q < W * H / 4; q += 64) {
+                        const int r = (4 * q) / W, c = (4 * q) % W;
+                        uint32_t* p = reinterpret_cast<uint32_t*>(base + r * stride + c);
+                        const uint32_t pv = *p;
+                        const int32_t* t4 = tg + r * P + c;
+                        uint32_t o = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) o |= (uint32_t)min(max((int32_t)((pv >> (8 * k)) & 255u) + t4[k], 0), 255) << (8 * k);
+                        *p = o;
+                    }
+                } else {
+                    for (int q = lane; q < W * H; q += 64) {
+                        const int r = q / W, c = q % W;
+                        uint8_t* p = base + r * stride + c;
+                        *p = (uint8_t)min(max((int32_t)*p + tg[r * P + c], 0), 255);
+                    }
                 }
             }
         }

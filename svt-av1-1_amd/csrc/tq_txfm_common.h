@@ -74,3 +74,19 @@ __device__ __forceinline__ void rot_q(int32_t* p, int al)
 }
 __device__ constexpr int8_t kVtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};  // vtx_tab (EbTransforms.h:88)
 __device__ constexpr int8_t kHtx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};  // htx_tab (:93)
+
+// Destination row of output r under the up-down flip of FLIPADST columns (only sizes up to 16 have ADST).  The row index is
+// made opaque: written as a select between y[H-1-r] and y[r] (or between two addresses) the compiler turns the flip into a
+// DYNAMIC index into the register array -- a 32-deep compare/select chain per element (2000 extra VALU instructions in the
+// 32x32 kernels) or a scratch array.
+template <int H>
+__device__ __forceinline__ int flip_row(int r, int kc)
+{
+    if constexpr (H > 16) {
+        return r;
+    } else {
+        int rr = (kc == 2) ? H - 1 - r : r;
+        asm volatile("" : "+v"(rr));
+        return rr;
+    }
+}

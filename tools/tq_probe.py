@@ -29,6 +29,14 @@ def main():
     rng = np.random.default_rng(1)
     res = torch.from_numpy(rng.integers(-255, 256, pic_w * pic_h, dtype=np.int16)).to("cuda:0")
     pred = torch.from_numpy(rng.integers(0, 256, pic_w * pic_h, dtype=np.uint8)).to("cuda:0")
+    src8 = torch.from_numpy(rng.integers(0, 256, pic_w * pic_h, dtype=np.uint8)).to("cuda:0")
+    qp = np.zeros((1, 10), np.int16)
+    for i, q in enumerate((40, 52)):   # one Quants / Dequants row, built like av1_build_quantizer
+        l = int(q).bit_length() - 1
+        qp[0, 4 + i] = np.int16(np.uint16((1 + (1 << (16 + l)) // q - (1 << 16)) & 0xffff)); qp[0, 6 + i] = 1 << (16 - l)
+        qp[0, 0 + i] = (84 * q + 64) >> 7; qp[0, 2 + i] = (64 * q) >> 7; qp[0, 8 + i] = q
+    d_qp = torch.from_numpy(qp).to("cuda:0")
+    d_iscan = torch.from_numpy(np.arange(1024, dtype=np.int16)).to("cuda:0")
     sizes = svtav1_hip.TX_SIZES_WH
     if args.sizes:
         sizes = [tuple(int(v) for v in s.split("x")) for s in args.sizes.split(",")]
@@ -68,7 +76,21 @@ def main():
         ib = n_tu * (win * hin * 4 + 2 * w * h)               # coefficients in + prediction read + reconstruction written
         print(f"inv_txfm {w:2d}x{h:2d}  n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gpix/s    {ib / ms / 1e6:8.1f} GB/s algorithmic",
               flush=True)
-        del d_out
+        # fused residual -> transform -> quantise -> dequantise -> inverse -> reconstruct (8-bit), in place on the prediction plane
+        tdesc = np.zeros(n_tu, dtype=svtav1_hip.TU_DESC_DTYPE)
+        tdesc["src_offset"], tdesc["pred_offset"], tdesc["recon_offset"] = off, off, off
+        tdesc["coeff_offset"] = idx * (win * hin)
+        tdesc["src_stride"], tdesc["pred_stride"], tdesc["recon_stride"] = pic_w, pic_w, pic_w
+        d_tdesc = torch.from_numpy(tdesc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        d_q = torch.empty(n_tu * win * hin, dtype=torch.int32, device="cuda:0")
+        d_eob = torch.empty(n_tu, dtype=torch.int16, device="cuda:0")
+        ms = timed(lambda: ctx.encode_tu_batch_dev(src8.data_ptr(), pred.data_ptr(), pred.data_ptr(), d_tdesc.data_ptr(), n_tu, w, h,
+                                                   d_qp.data_ptr(), d_iscan.data_ptr(), None, d_q.data_ptr(), None, d_eob.data_ptr(),
+                                                   None, None, stream))
+        eb = n_tu * (2 * w * h + w * h + win * hin * (2 + 4))    # source + prediction in, reconstruction out, iscan in, qcoeff out
+        print(f"encode_tu {w:2d}x{h:2d} n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gpix/s    {eb / ms / 1e6:8.1f} GB/s algorithmic",
+              flush=True)
+        del d_out, d_q
 
 
 if __name__ == "__main__":
