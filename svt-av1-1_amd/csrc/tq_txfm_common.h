@@ -17,11 +17,19 @@ constexpr int clog2(int n)
     return l;
 }
 
+// half_btf: round_shift(w0 * a + w1 * b, BIT) with a 64-bit sum.  Exactly three VALU instructions: two v_mad_i64_i32 (the
+// rounding constant rides in as the first accumulator) and one v_alignbit_b32 for the shift.  Left to the compiler the same
+// expression costs 5-6 (separate 64-bit adds for the rounding term, mixed u64/i24 multiply expansions), and the transform
+// kernels are VALU-bound.  w0 / w1 are compile-time cosines: they live in SGPRs (one scalar operand per VOP3
+// instruction on gfx9), the rounding constant in a VGPR pair.
 template <int BIT>
 __device__ __forceinline__ int32_t hb(int32_t w0, int32_t a, int32_t w1, int32_t b)
 {
-    const int64_t s = (int64_t)w0 * a + (int64_t)w1 * b + ((int64_t)1 << (BIT - 1));
-    return (int32_t)(s >> BIT);
+    const int64_t rnd = (int64_t)1 << (BIT - 1);  // one VGPR pair shared by every rotation of the kernel
+    int64_t t, u;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(t) : "s"(w0), "v"(a), "v"(rnd) : "vcc");
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(u) : "s"(w1), "v"(b), "v"(t) : "vcc");
+    return (int32_t)__builtin_amdgcn_alignbit((uint32_t)(u >> 32), (uint32_t)u, BIT);
 }
 template <int BIT>
 __device__ __forceinline__ int32_t rs(int64_t v)
