@@ -365,6 +365,15 @@ int32_t svthip_encode_tu_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, const 
                                    int32_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_three_quad_energy, uint64_t *d_distortion,
                                    void *stream);
 
+/* The same chain for 10-bit video held in 16-bit planes (offsets and strides of the descriptors in SAMPLES): high-bit-depth
+ * quantiser (highbd_quantize_b_helper_c, no int16 clamp), inverse transform with bd = 10 (Av1InvTransformRecon,
+ * Codec/EbTransforms.c:8344-8372), reconstruction clipped to 0..1023. */
+int32_t svthip_encode_tu16_batch_dev(svthip_ctx *ctx, const uint16_t *d_src, const uint16_t *d_pred, uint16_t *d_recon,
+                                     const svthip_tu_desc *d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                     const int16_t *d_qparams, const int16_t *d_iscan, int32_t *d_coeff, int32_t *d_qcoeff,
+                                     int32_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_three_quad_energy, uint64_t *d_distortion,
+                                     void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

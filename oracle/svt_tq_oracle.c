@@ -499,3 +499,26 @@ void orc_encode_tu(const uint8_t *src, int32_t src_stride, const uint8_t *pred, 
     for (int r = 0; r < h; r++)
         for (int c = 0; c < w; c++) recon[r * recon_stride + c] = (uint8_t)rec16[r * w + c];
 }
+
+/* the same chain for 10-bit samples in 16-bit planes: ResidualKernel16bit (EbPictureOperators.c:225-255), high-bit-depth
+ * quantiser, Av1InvTransformRecon with bd = 10 (EbTransforms.c:8344-8372) */
+void orc_encode_tu16(const uint16_t *src, int32_t src_stride, const uint16_t *pred, int32_t pred_stride, uint16_t *recon,
+                     int32_t recon_stride, int w, int h, int tx_type, const int16_t *qp, const int16_t *scan, int32_t *coeff,
+                     int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, uint64_t *three_quad_energy, uint64_t dist[2])
+{
+    static __thread int16_t residual[64 * 64];
+    static __thread int32_t full[64 * 64];
+    static __thread uint16_t rec16[64 * 64];
+    const int win = w > 32 ? 32 : w, hin = h > 32 ? 32 : h;
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) residual[r * w + c] = (int16_t)((int)src[r * src_stride + c] - (int)pred[r * pred_stride + c]);
+    orc_fwd_txfm2d(residual, w, w, h, tx_type, full);
+    *three_quad_energy = orc_pack_transform(full, w, h, coeff);
+    orc_quantize_b(coeff, win * hin, qp, scan, orc_tx_log_scale(w, h), 1, qcoeff, dqcoeff, eob);
+    orc_full_distortion(coeff, dqcoeff, win * hin, dist);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) rec16[r * w + c] = pred[r * pred_stride + c];
+    if (*eob) orc_inv_txfm2d_add(dqcoeff, rec16, w, w, h, tx_type, 10);
+    for (int r = 0; r < h; r++)
+        for (int c = 0; c < w; c++) recon[r * recon_stride + c] = rec16[r * w + c];
+}

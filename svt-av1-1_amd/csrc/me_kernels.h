@@ -57,9 +57,9 @@ hipError_t launch_fwd_txfm2d(const int16_t* residual, const svthip_txfm_desc* de
 hipError_t launch_inv_txfm2d_add(const int32_t* coeff, const svthip_itxfm_desc* desc, uint32_t n_tu, int w, int h, int bd,
                                  void* recon, int recon_16bit, hipStream_t s);
 
-hipError_t launch_encode_tu(const uint8_t* src, const uint8_t* pred, uint8_t* recon, const svthip_tu_desc* desc, uint32_t n_tu, int w,
-                            int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff,
-                            uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s);
+hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int planes_16bit, const svthip_tu_desc* desc, uint32_t n_tu,
+                            int w, int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff,
+                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s);
 
 __global__ void me_search_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P, uint32_t list_index,
                                  const svthip_sb_origin* __restrict__ sbs, const uint32_t* __restrict__ l0_best_mv64,

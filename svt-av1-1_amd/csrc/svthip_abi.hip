@@ -248,11 +248,10 @@ int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff,
     return SVTHIP_OK;
 }
 
-int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const uint8_t* d_pred, uint8_t* d_recon,
-                                   const svthip_tu_desc* d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
-                                   const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
-                                   int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion,
-                                   void* stream)
+static int32_t encode_tu_common(svthip_ctx* ctx, const void* d_src, const void* d_pred, void* d_recon, int planes_16bit,
+                                const svthip_tu_desc* d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
+                                int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
@@ -265,10 +264,32 @@ int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const 
     if (reinterpret_cast<uintptr_t>(d_iscan) & 7u) return fail(SVTHIP_ERR_BAD_PARAMETER, "iscan pool must be 8-byte aligned%s", "");
     if ((reinterpret_cast<uintptr_t>(d_three_quad_energy) | reinterpret_cast<uintptr_t>(d_distortion)) & 7u)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "energy / distortion outputs must be 8-byte aligned%s", "");
+    if (planes_16bit && ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_pred) | reinterpret_cast<uintptr_t>(d_recon)) & 1u))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "16-bit planes must be 2-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qparams, d_iscan, d_coeff,
-                                     d_qcoeff, d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, s));
+    HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qparams, d_iscan,
+                                     d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, s));
     return SVTHIP_OK;
+}
+
+int32_t svthip_encode_tu_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, const uint8_t* d_pred, uint8_t* d_recon,
+                                   const svthip_tu_desc* d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                   const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
+                                   int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion,
+                                   void* stream)
+{
+    return encode_tu_common(ctx, d_src, d_pred, d_recon, 0, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan, d_coeff, d_qcoeff,
+                            d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, stream);
+}
+
+int32_t svthip_encode_tu16_batch_dev(svthip_ctx* ctx, const uint16_t* d_src, const uint16_t* d_pred, uint16_t* d_recon,
+                                     const svthip_tu_desc* d_desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height,
+                                     const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
+                                     int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion,
+                                     void* stream)
+{
+    return encode_tu_common(ctx, d_src, d_pred, d_recon, 1, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan, d_coeff, d_qcoeff,
+                            d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, stream);
 }
 
 static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur, const svthip_pa_picture* ref,

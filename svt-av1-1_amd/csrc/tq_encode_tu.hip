@@ -50,9 +50,11 @@ __device__ __forceinline__ int group_max_i32(int v)
     return v;
 }
 
-template <int WL, int HL>
-__global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restrict__ src, const uint8_t* pred,
-                                                        uint8_t* recon, const svthip_tu_desc* __restrict__ desc, uint32_t n_tu,
+// PIX = uint8_t: 8-bit planes (bd 8, quantize_b_helper_c_II); PIX = uint16_t: 10-bit samples in 16-bit planes (bd 10,
+// highbd_quantize_b_helper_c, Av1InvTransformRecon)
+template <int WL, int HL, typename PIX>
+__global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ src, const PIX* pred,
+                                                        PIX* recon, const svthip_tu_desc* __restrict__ desc, uint32_t n_tu,
                                                         const int16_t* __restrict__ qparams, const int16_t* __restrict__ iscan_pool,
                                                         int32_t* __restrict__ coeff_out, int32_t* __restrict__ qcoeff_out,
                                                         int32_t* __restrict__ dqcoeff_out, uint16_t* __restrict__ eob_out,
@@ -69,9 +71,10 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
     extern __shared__ int32_t lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int32_t* tile = lds_all + wave * (G * H * P);
-    const Clamp cl_in = {-(1 << 15), (1 << 15) - 1};   // bd + 8 = 16 bits
-    const Clamp cl_col = {-(1 << 15), (1 << 15) - 1};  // max(bd + 6, 16) = 16 bits
-    constexpr int32_t res_max = (1 << 15) - 1 + (914 << 1);
+    constexpr int BD = sizeof(PIX) == 1 ? 8 : 10, HIGHBD = sizeof(PIX) == 1 ? 0 : 1;
+    const Clamp cl_in = {-(1 << (BD + 7)), (1 << (BD + 7)) - 1};  // bd + 8 bits
+    const Clamp cl_col = {-(1 << 15), (1 << 15) - 1};             // max(bd + 6, 16) = 16 bits for bd 8 and 10
+    constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), pix_max = (1 << BD) - 1;
     const uint32_t groups = (n_tu + G - 1) / G;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
         // ---- A: residual + forward column pass ----
@@ -81,8 +84,8 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
             if (g < G && tu < n_tu) {
                 const svthip_tu_desc d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
-                const uint8_t* s = src + d.src_offset + c;
-                const uint8_t* p = pred + d.pred_offset + c;
+                const PIX* s = src + d.src_offset + c;
+                const PIX* p = pred + d.pred_offset + c;
                 const int ss = d.src_stride, ps = d.pred_stride;
                 int32_t x[H], y[H];
 #pragma unroll
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
                         int32_t qv[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            quant_one(y[c + k], (r | (c + k)) != 0, zb, rnd, qp, LOG_SCALE, 0, qv[k], dq[c + k]);
+                            quant_one(y[c + k], (r | (c + k)) != 0, zb, rnd, qp, LOG_SCALE, HIGHBD, qv[k], dq[c + k]);
                             if (qv[k] != 0) last = max(last, isv[k] + 1);
                             const int64_t dd = (int64_t)y[c + k] - dq[c + k];
                             dist_res += (uint64_t)(dd * dd);
@@ -198,8 +201,8 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
 #pragma unroll
                 for (int r = HIN; r < H; r++) x[r] = 0;
                 itxfm1d<H, HIN>(kc, x, y, cl_col);
-                const uint8_t* p = pred + d.pred_offset + c;
-                uint8_t* out = recon + d.recon_offset + c;
+                const PIX* p = pred + d.pred_offset + c;
+                PIX* out = recon + d.recon_offset + c;
                 const int ps = d.pred_stride, rs_ = d.recon_stride;
 #pragma unroll
                 for (int r = 0; r < H; r++) {
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
                     t = min(max(t, -res_max - 1), res_max);
                     const int rr = flip_row<H>(r, kc);
                     const int32_t v = (int32_t)p[rr * ps] + t;
-                    out[rr * rs_] = (uint8_t)min(max(v, 0), 255);
+                    out[rr * rs_] = (PIX)min(max(v, 0), pix_max);
                 }
             }
         }
@@ -217,8 +220,8 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const uint8_t* __restric
     }
 }
 
-template <int WL, int HL>
-hipError_t launch_one(const uint8_t* src, const uint8_t* pred, uint8_t* recon, const svthip_tu_desc* desc, uint32_t n_tu,
+template <int WL, int HL, typename PIX>
+hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_tu_desc* desc, uint32_t n_tu,
                       const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
                       uint64_t* energy, uint64_t* dist, hipStream_t s)
 {
@@ -228,24 +231,24 @@ hipError_t launch_one(const uint8_t* src, const uint8_t* pred, uint8_t* recon, c
     uint32_t blocks = (groups + 3) / 4;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     if (lds > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL>),
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((encode_tu_kernel<WL, HL>), dim3(blocks), dim3(256), lds, s, src, pred, recon, desc, n_tu, qparams, iscan, coeff,
+    hipLaunchKernelGGL((encode_tu_kernel<WL, HL, PIX>), dim3(blocks), dim3(256), lds, s, src, pred, recon, desc, n_tu, qparams, iscan, coeff,
                        qcoeff, dqcoeff, eob, energy, dist);
     return hipGetLastError();
 }
 
-}  // namespace
-
-hipError_t launch_encode_tu(const uint8_t* src, const uint8_t* pred, uint8_t* recon, const svthip_tu_desc* desc, uint32_t n_tu, int w,
-                            int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff,
-                            uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s)
+template <typename PIX>
+hipError_t launch_sized(const PIX* src, const PIX* pred, PIX* recon, const svthip_tu_desc* desc, uint32_t n_tu, int w, int h,
+                        const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
+                        uint64_t* energy, uint64_t* dist, hipStream_t s)
 {
     const int key = clog2(w) * 8 + clog2(h);
 #define CASE(WL, HL) \
-    case (WL) * 8 + (HL): return launch_one<WL, HL>(src, pred, recon, desc, n_tu, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s)
+    case (WL) * 8 + (HL): \
+        return launch_one<WL, HL, PIX>(src, pred, recon, desc, n_tu, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s)
     switch (key) {
         CASE(2, 2); CASE(3, 3); CASE(4, 4); CASE(5, 5); CASE(6, 6);
         CASE(2, 3); CASE(3, 2); CASE(3, 4); CASE(4, 3); CASE(4, 5); CASE(5, 4); CASE(5, 6); CASE(6, 5);
@@ -253,6 +256,19 @@ hipError_t launch_encode_tu(const uint8_t* src, const uint8_t* pred, uint8_t* re
         default: return hipErrorInvalidValue;
     }
 #undef CASE
+}
+
+}  // namespace
+
+hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int planes_16bit, const svthip_tu_desc* desc, uint32_t n_tu,
+                            int w, int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff,
+                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s)
+{
+    if (planes_16bit)
+        return launch_sized<uint16_t>(static_cast<const uint16_t*>(src), static_cast<const uint16_t*>(pred), static_cast<uint16_t*>(recon),
+                                      desc, n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s);
+    return launch_sized<uint8_t>(static_cast<const uint8_t*>(src), static_cast<const uint8_t*>(pred), static_cast<uint8_t*>(recon), desc,
+                                 n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s);
 }
 
 }  // namespace svthip

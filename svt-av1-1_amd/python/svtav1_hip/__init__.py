@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
     L.svthip_inv_txfm2d_add_batch_dev.restype = C.c_int32
     L.svthip_inv_txfm2d_add_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                   C.c_uint32, C.c_void_p, C.c_void_p]
+    L.svthip_encode_tu16_batch_dev.restype = C.c_int32
+    L.svthip_encode_tu16_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                               C.c_uint32] + [C.c_void_p] * 9
     L.svthip_encode_tu_batch_dev.restype = C.c_int32
     L.svthip_encode_tu_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                              C.c_uint32] + [C.c_void_p] * 9
@@ -268,9 +271,10 @@ Context.inv_txfm2d_add_batch_dev = _inv_txfm2d_add_batch_dev
 
 
 def _encode_tu_batch_dev(self, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan, d_coeff, d_qcoeff,
-                         d_dqcoeff, d_eob, d_energy=None, d_dist=None, stream=None):
-    _check(lib().svthip_encode_tu_batch_dev(self._h, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan,
-                                            d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_energy, d_dist, stream))
+                         d_dqcoeff, d_eob, d_energy=None, d_dist=None, stream=None, planes_16bit=False):
+    fn = lib().svthip_encode_tu16_batch_dev if planes_16bit else lib().svthip_encode_tu_batch_dev
+    _check(fn(self._h, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, tx_height, d_qparams, d_iscan,
+              d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_energy, d_dist, stream))
 
 
 Context.encode_tu_batch_dev = _encode_tu_batch_dev

@@ -168,3 +168,34 @@ def test_encode_tu_optional_outputs_may_be_null(hip_ctx, oracle):
     hip_ctx.synchronize()
     assert np.array_equal(d_q.cpu().numpy(), ref["qcoeff"])
     assert np.array_equal(d_pred.cpu().numpy(), ref["recon"])
+
+
+@pytest.mark.parametrize("size", [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32), (64, 32)])
+def test_encode_tu16_batch_matches_oracle(hip_ctx, oracle, size):
+    """Fused chain on 10-bit samples in 16-bit planes (high-bit-depth quantiser, bd = 10 inverse transform), in place."""
+    torch = pytest.importorskip("torch")
+    w, h = size
+    n_tu = 53 if w * h <= 1024 else 21
+    rng = np.random.default_rng(w * 100 + h + 7)
+    b = random_encode_batch(rng, n_tu, w, h, bit_depth=10)
+    ref = oracle_encode_batch(oracle, b)
+    n = b["n"]
+    d_src, d_pred, d_desc, d_qp, d_iscan = _dev(b["src"]), _dev(b["pred"]), _dev(b["desc"]), _dev(b["qparams"]), _dev(b["iscan"])
+    d_coeff = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_q = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_dq = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_eob = torch.full((n_tu,), -1, dtype=torch.int16, device="cuda:0")
+    d_en = torch.full((n_tu,), -1, dtype=torch.int64, device="cuda:0")
+    d_dist = torch.full((n_tu, 2), -1, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.encode_tu_batch_dev(d_src.data_ptr(), d_pred.data_ptr(), d_pred.data_ptr(), d_desc.data_ptr(), n_tu, w, h, d_qp.data_ptr(),
+                                d_iscan.data_ptr(), d_coeff.data_ptr(), d_q.data_ptr(), d_dq.data_ptr(), d_eob.data_ptr(),
+                                d_en.data_ptr(), d_dist.data_ptr(), planes_16bit=True)
+    hip_ctx.synchronize()
+    assert np.array_equal(d_coeff.cpu().numpy(), ref["coeff"])
+    assert np.array_equal(d_q.cpu().numpy(), ref["qcoeff"])
+    assert np.array_equal(d_dq.cpu().numpy(), ref["dqcoeff"])
+    assert np.array_equal(d_eob.cpu().numpy().view(np.uint16), ref["eob"])
+    assert np.array_equal(d_en.cpu().numpy().view(np.uint64), ref["energy"])
+    assert np.array_equal(d_dist.cpu().numpy().view(np.uint64), ref["dist"])
+    assert np.array_equal(d_pred.cpu().numpy().view(np.uint16), ref["recon"])

@@ -148,20 +148,23 @@ def oracle_itxfm_batch(oracle, b):
     return rec.astype(b["pred"].dtype)
 
 
-def random_encode_batch(rng, n_tu, w, h, pic_w=512, pic_h=256):
-    """Source / prediction planes and TU descriptors for the fused encode chain; TUs do not overlap."""
+def random_encode_batch(rng, n_tu, w, h, pic_w=512, pic_h=256, bit_depth=8):
+    """Source / prediction planes and TU descriptors for the fused encode chain; TUs do not overlap.  bit_depth 10 gives
+    uint16 planes with 10-bit samples."""
     win, hin = min(w, 32), min(h, 32)
     n = win * hin
     yy, xx = np.mgrid[0:pic_h, 0:pic_w]
     base = 128 + 70 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
-    src = np.clip(base + rng.normal(0, 6, (pic_h, pic_w)), 0, 255).astype(np.uint8)
-    pred = np.clip(base + rng.normal(0, 10, (pic_h, pic_w)) + 8 * np.sin(xx / 3.0), 0, 255).astype(np.uint8)
-    pred[: pic_h // 8] = rng.integers(0, 256, (pic_h // 8, pic_w))            # large residuals
+    sc = 1 << (bit_depth - 8)
+    dt = np.uint8 if bit_depth == 8 else np.uint16
+    src = np.clip(sc * (base + rng.normal(0, 6, (pic_h, pic_w))), 0, 256 * sc - 1).astype(dt)
+    pred = np.clip(sc * (base + rng.normal(0, 10, (pic_h, pic_w)) + 8 * np.sin(xx / 3.0)), 0, 256 * sc - 1).astype(dt)
+    pred[: pic_h // 8] = rng.integers(0, 256 * sc, (pic_h // 8, pic_w))       # large residuals
     pred[-pic_h // 4:] = src[-pic_h // 4:]                                     # zero residuals -> eob 0
     per_row = pic_w // w
     slots = rng.permutation(per_row * (pic_h // h))[:n_tu]
     n_rows = 8
-    qparams = np.stack([make_qparams(int(rng.integers(4, 400)), int(rng.integers(4, 500))) for _ in range(n_rows)])
+    qparams = np.stack([make_qparams(int(rng.integers(4, 400)) * sc, int(rng.integers(4, 500)) * sc) for _ in range(n_rows)])
     scans, iscans = [], []
     for v in range(3):
         sc = rng.permutation(n).astype(np.int16)
@@ -177,11 +180,13 @@ def random_encode_batch(rng, n_tu, w, h, pic_w=512, pic_h=256):
         desc[i]["src_stride"] = pic_w; desc[i]["pred_stride"] = pic_w; desc[i]["recon_stride"] = pic_w
         desc[i]["qparam_index"] = int(rng.integers(0, n_rows)); desc[i]["tx_type"] = types[int(rng.integers(0, len(types)))]
     return {"src": src.reshape(-1), "pred": pred.reshape(-1), "desc": desc, "qparams": qparams, "scan": np.concatenate(scans),
-            "iscan": np.concatenate(iscans), "w": w, "h": h, "n": n}
+            "iscan": np.concatenate(iscans), "w": w, "h": h, "n": n, "bit_depth": bit_depth}
 
 
 def oracle_encode_batch(oracle, b):
-    orc = oracle.lib.orc_encode_tu
+    wide = b.get("bit_depth", 8) != 8
+    es = 2 if wide else 1          # bytes per sample
+    orc = oracle.lib.orc_encode_tu16 if wide else oracle.lib.orc_encode_tu
     orc.restype = None
     orc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8
     n_tu, n = len(b["desc"]), b["n"]
@@ -192,8 +197,8 @@ def oracle_encode_batch(oracle, b):
         co = int(d["coeff_offset"])
         qp = np.ascontiguousarray(b["qparams"][int(d["qparam_index"])])
         sc = np.ascontiguousarray(b["scan"][int(d["iscan_offset"]):int(d["iscan_offset"]) + n])
-        orc(b["src"].ctypes.data + int(d["src_offset"]), int(d["src_stride"]), b["pred"].ctypes.data + int(d["pred_offset"]),
-            int(d["pred_stride"]), out["recon"].ctypes.data + int(d["recon_offset"]), int(d["recon_stride"]), b["w"], b["h"],
+        orc(b["src"].ctypes.data + es * int(d["src_offset"]), int(d["src_stride"]), b["pred"].ctypes.data + es * int(d["pred_offset"]),
+            int(d["pred_stride"]), out["recon"].ctypes.data + es * int(d["recon_offset"]), int(d["recon_stride"]), b["w"], b["h"],
             int(d["tx_type"]), qp.ctypes.data, sc.ctypes.data, out["coeff"].ctypes.data + 4 * co, out["qcoeff"].ctypes.data + 4 * co,
             out["dqcoeff"].ctypes.data + 4 * co, out["eob"].ctypes.data + 2 * i, out["energy"].ctypes.data + 8 * i,
             out["dist"].ctypes.data + 16 * i)

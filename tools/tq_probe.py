@@ -91,6 +91,20 @@ def main():
         print(f"encode_tu {w:2d}x{h:2d} n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gpix/s    {eb / ms / 1e6:8.1f} GB/s algorithmic",
               flush=True)
         del d_out, d_q
+    # stand-alone quantiser: 1024-coefficient TUs (32x32 class), 14 B per coefficient (4 in, 2 iscan, 4 + 4 out)
+    n_tu = args.coeffs // 1024
+    qd = np.zeros(n_tu, dtype=svtav1_hip.QUANT_DESC_DTYPE)
+    qd["coeff_offset"] = np.arange(n_tu) * 1024
+    qd["n_coeffs"] = 1024
+    qd["log_scale"] = 1
+    d_qd = torch.from_numpy(qd.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    d_c = torch.from_numpy(rng.integers(-2000, 2001, n_tu * 1024, dtype=np.int32)).to("cuda:0")
+    d_qo = torch.empty_like(d_c); d_dq = torch.empty_like(d_c)
+    d_eob = torch.empty(n_tu, dtype=torch.int16, device="cuda:0")
+    ms = timed(lambda: ctx.quantize_b_batch_dev(d_c.data_ptr(), d_qd.data_ptr(), n_tu, d_qp.data_ptr(), d_iscan.data_ptr(), d_qo.data_ptr(),
+                                                d_dq.data_ptr(), d_eob.data_ptr(), stream))
+    nc = n_tu * 1024
+    print(f"quantize_b 1024-coeff TUs  n_tu {n_tu:8d}  {ms:8.4f} ms  {nc / ms / 1e6:8.2f} Gcoeff/s  {nc * 14 / ms / 1e6:8.1f} GB/s algorithmic", flush=True)
 
 
 if __name__ == "__main__":
