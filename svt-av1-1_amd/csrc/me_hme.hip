@@ -6,12 +6,11 @@
 // MotionEstimateLcu (Source/Lib/Codec/EbMotionEstimation.c:6300-6738, :5882-6145, :4306-4758, :5466-5552).
 // Output: one svthip_fullpel_desc per SB for fullpel85_kernel (me_fullpel.hip).
 //
-// Mapping: one 256-thread workgroup per SB; wave r owns HME search region r (regions are independent
-// through all three levels), lanes own search positions.  Every level is the reference's SadLoopKernel
-// (C_DEFAULT/EbComputeSAD_C.c:73-119): exhaustive SAD over a small window, strict '<' in raster order,
-// which a 64-bit (sad << 32 | raster index) wave-min reproduces exactly.  The 1/16 and 1/4 planes are a
-// few hundred KB and stay in L2, so windows are read straight from global memory with (hardware-
-// supported) unaligned dword loads and v_sad_u8; the levels are ~20 % of the full-pel search's work.
+// Mapping: one 256-thread workgroup per SB, blockIdx.y = job (a current / reference picture pair of the launch's job
+// table); wave r owns HME search region r (regions are independent through all three levels), lanes own search positions.
+// Every level is the reference's SadLoopKernel (C_DEFAULT/EbComputeSAD_C.c:73-119): exhaustive SAD over a small window,
+// strict '<' in raster order, which a (sad << k | raster index) wave-min reproduces exactly.  The block and a band of the
+// window are staged in a per-wave LDS slice; SADs are v_qsad_pk_u16_u8 on LDS dwords (me_hme_impl.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
