@@ -374,6 +374,18 @@ int32_t svthip_encode_tu16_batch_dev(svthip_ctx *ctx, const uint16_t *d_src, con
                                      int32_t *d_dqcoeff, uint16_t *d_eob, uint64_t *d_three_quad_energy, uint64_t *d_distortion,
                                      void *stream);
 
+/* 209-PU mode of the same search (pic_depth_mode <= PIC_ALL_C_DEPTH_MODE): open_loop_me_fullpel_search_sblock +
+ * ExtSadCalculation_8x8_16x16 / ExtSadCalculation_32x32_64x64 / ExtSadCalculation
+ * (Source/Lib/Codec/EbMotionEstimation.c:1556-1595, :1065-1231, :159-1052): the 85 square PUs plus the 124 rectangular ones
+ * (64x32, 32x16, 16x8, 32x64, 16x32, 8x16, 32x8, 8x32, 64x16, 16x64), d_best_sad / d_best_mv = [n_sb][209] in the reference's
+ * ME-buffer order (Codec/EbMotionEstimationContext.h:42-265), including the reference's stale-variable update of PU 92
+ * (32x16[5], :343-347).  Same descriptors and window rules as svthip_me_fullpel_search_dev.  Sub-pel refinement and
+ * bi-prediction of the rectangular PUs are not built yet. */
+int32_t svthip_me_fullpel_search209_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                        const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
+                                        uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                        uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

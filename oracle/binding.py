@@ -59,6 +59,20 @@ class Oracle:
                                           _ptr(sad, u32p), _ptr(mv, u32p))
         return sad, mv
 
+    def fullpel_search209_batch(self, src_plane, ref_plane, desc, src_stride=None, ref_stride=None):
+        """209-PU mode (squares + rectangles): -> (sad[n,209], mv[n,209]) in ME-buffer order."""
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n = desc.shape[0]
+        sad = np.empty((n, 209), dtype=np.uint32)
+        mv = np.empty((n, 209), dtype=np.uint32)
+        ss = src_stride if src_stride is not None else src_plane.shape[1]
+        rs = ref_stride if ref_stride is not None else ref_plane.shape[1]
+        f = self.lib.orc_fullpel_search209_batch
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        f(src_plane.ctypes.data, ss, ref_plane.ctypes.data, rs, desc.ctypes.data, n, sad.ctypes.data, mv.ctypes.data)
+        return sad, mv
+
     def hme_search_center_batch(self, pool, cur, ref, params, list_index, sb, l0_best_mv64=None, hme_state=None):
         """-> (desc int32 [n,6], center int16 [n,2]); cur/ref are svtav1_hip.PaPictureDesc, params MeParams."""
         sb = np.ascontiguousarray(sb, dtype=np.uint16)
@@ -203,6 +217,22 @@ class ReferenceME:
         self.lib.ref_me_lcu_run.restype = C.c_int
         self.lib.ref_me_lcu_run.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+
+    def fullpel_search209_batch(self, src_plane, ref_plane, desc):
+        """The reference's ExtSadCalculation* functions driven like open_loop_me_fullpel_search_sblock
+        (oracle/ref_fullpel209_driver.c) -> (sad[n,209], mv[n,209])."""
+        f = self.lib.ref_fullpel_search_209pu
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int16, C.c_int16, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n = desc.shape[0]
+        sad = np.full((n, 209), 128 * 128 * 255, dtype=np.uint32)
+        mv = np.zeros((n, 209), dtype=np.uint32)
+        for i in range(n):
+            d = desc[i]
+            f(src_plane.ctypes.data + int(d[0]), src_plane.shape[1], ref_plane.ctypes.data + int(d[1]), ref_plane.shape[1], int(d[2]), int(d[3]),
+              int(d[4]), int(d[5]), sad[i].ctypes.data, mv[i].ctypes.data)
+        return sad, mv
 
     def interp_region(self, ref_plane, ref_off, sw, sh, rows, cols):
         """The reference's InterpolateSearchRegionAVC on the region whose position (0,0) is ref_plane.flat[ref_off];

@@ -1,0 +1,480 @@
+// svt-av1-1_amd/csrc/me_fullpel209_impl.h -- 209-PU full-pel search (85 square + 124 rectangular PUs) of one superblock by
+// one 256-thread workgroup: open_loop_me_fullpel_search_sblock / open_loop_me_get_search_point_results_block
+// (Source/Lib/Codec/EbMotionEstimation.c:1556-1595, :1065-1231) with ExtSadCalculation_8x8_16x16 (:159-212),
+// ExtSadCalculation_32x32_64x64 (:218-260) and ExtSadCalculation (:266-1052).
+//
+// The square part is the 85-PU kernel (me_fullpel_impl.h).  Rectangles are sums of the stored square SADs:
+//   inside a wave's 32x32 quadrant: 16x8, 8x16 (two per 16x16), 32x8, 8x32 (four per quadrant), 32x16, 16x32 (two per quadrant)
+//     -- packed-u16 adds of the 8x8 / 16x16 accumulators and the same (sad << 16 | idx) key minimum (all <= 65280);
+//   across quadrants: 64x32, 32x64 (from the exchanged 32x32 sums), 64x16, 16x64 (two more exchange rounds through the same
+//     16 KB buffer with the packed 32x16 / 16x32 sums) -- (raw << 14 | idx) keys, finished by wave Q for positions 4Q..4Q+3.
+// PU 92 (32x16[5], bottom half of quadrant 2) follows the reference's stale-variable update (:343-347): it is overwritten
+// with the current SAD whenever the SAD of 64x32[1] at that position is below the stored best.  That is a sequential
+// recurrence over raster order, resolved per iteration by wave 0 from the per-position (64x32[1], 32x16[5]) pairs in LDS:
+// "first later position whose 64x32[1] SAD is below the current best" repeated until none (the best strictly decreases).
+// Included inside namespace svthip { namespace { namespace fp209 { ... } } }.
+#pragma once
+
+
+constexpr int kPitch = SVTHIP_FULLPEL_LDS_PITCH;  // bytes per window row in LDS
+
+__device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// keys for the four positions of a quad from packed u16 SADs (lo: slots 0,1  hi: slots 2,3)
+__device__ __forceinline__ uint32_t track4(uint32_t best, uint64_t acc, const uint32_t* idx, uint32_t himask)
+{
+    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    uint32_t k0 = (lo << 16) | idx[0];
+    uint32_t k1 = (lo & himask) | idx[1];
+    uint32_t k2 = (hi << 16) | idx[2];
+    uint32_t k3 = (hi & himask) | idx[3];
+    best = min3u(best, k0, k1);
+    best = min3u(best, k2, k3);
+    return best;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        uint32_t o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        unsigned long long o = __shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t mv_word(int x, int y)
+{
+    // (uint16)(4*y) << 16 | (uint16)(4*x), Codec/EbMotionEstimation.c:1389-1391
+    return ((uint32_t)(uint16_t)(y * 4) << 16) | (uint32_t)(uint16_t)(x * 4);
+}
+
+
+constexpr int kFp209Fixed = 16384 + 8192 + 128;  // exchange buffer, (64x32[1], 32x16[5]) pairs, cross-quadrant results
+
+// d: the superblock's descriptor (6 int32: src_offset, ref_offset, x/y search origin, search width/height), any address space;
+// smem: kFp209Fixed + (sh + 63) * SVTHIP_FULLPEL_LDS_PITCH bytes of workgroup LDS, 16-byte aligned.
+// Results go to out_sad / out_mv [209 * sbi ...] in ME-buffer order.  Must be called by all 256 threads.
+__device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                             const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* d, uint32_t sbi,
+                                             uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv, uint8_t* smem)
+{
+    // LDS layout: [0,16K) exchange buffer, [16K,24K) per-position 64x32[1] / 32x16[5] SADs of the current iteration,
+    // [24K,24K+128) cross-quadrant results, then the window.
+    uint32_t* xch = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* qa = reinterpret_cast<uint32_t*>(smem + 16384);          // [64 lanes][16 positions] 64x32[1]
+    uint32_t* qv = reinterpret_cast<uint32_t*>(smem + 16384 + 4096);   // [64 lanes][16 positions] 32x16[5]
+    unsigned long long* best64_lds = reinterpret_cast<unsigned long long*>(smem + 24576);
+    uint32_t* cross_lds = reinterpret_cast<uint32_t*>(smem + 24576 + 16);  // 12 keys: 64x32[2] 32x64[2] 64x16[4] 16x64[4]
+    uint8_t* win = smem + kFp209Fixed;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int Q = __builtin_amdgcn_readfirstlane(tid >> 6);  // quadrant = wave index
+    const int Qx = Q & 1, Qy = Q >> 1;
+
+    // wave-uniform by construction; readfirstlane keeps them in SGPRs also when the descriptor is read from LDS
+    const int src_off = __builtin_amdgcn_readfirstlane(d[0]);
+    const int ref_off = __builtin_amdgcn_readfirstlane(d[1]);
+    const int xo = __builtin_amdgcn_readfirstlane(d[2]), yo = __builtin_amdgcn_readfirstlane(d[3]);
+    const int sw = __builtin_amdgcn_readfirstlane(d[4]), sh = __builtin_amdgcn_readfirstlane(d[5]);
+    const int n_xg = (sw + 15) >> 4;
+
+    // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
+    {
+        const uint8_t* base = ref_plane + ref_off;
+        const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 3u);
+        const uint32_t* base4 = reinterpret_cast<const uint32_t*>(base - a);
+        const int rows = sh + 63;
+        const int ndw_valid = (sw + 63 + 3) >> 2;
+        const int ndw_row = kPitch >> 2;
+        const int rstride4 = ref_stride >> 2;
+        const int total = rows * ndw_row;
+        for (int i = tid; i < total; i += 256) {
+            int r = i / ndw_row;
+            int c = i - r * ndw_row;
+            uint32_t v = 0;
+            if (c < ndw_valid) {
+                const uint32_t* p = base4 + (size_t)r * rstride4 + c;
+                uint32_t lo = p[0];
+                uint32_t hi = a ? p[1] : 0u;
+                v = __builtin_amdgcn_alignbyte(hi, lo, a);
+            }
+            reinterpret_cast<uint32_t*>(win)[i] = v;
+        }
+        if (tid == 0) *best64_lds = ~0ull;
+        if (tid < 12) cross_lds[tid] = 0xffffffffu;
+    }
+    __syncthreads();
+
+    // source pixels of this wave's quadrant (wave-uniform -> scalar loads)
+    const uint32_t* src4 = reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)(32 * Qy) * src_stride + 32 * Qx);
+    const int sstride4 = src_stride >> 2;
+
+    uint32_t best8[16], best16[4], best32 = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 16; i++) best8[i] = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) best16[i] = 0xffffffffu;
+    uint32_t best64_raw = 0xffffffffu, best64_idx = 0;
+    // rectangles inside the quadrant: 16x8 / 8x16 [2 * zz + part], 32x8 [2 * R + part], 8x32 [2 * C + side], 32x16 [R], 16x32 [C]
+    uint32_t b16x8[8], b8x16[8], b32x8[4], b8x32[4], b32x16[2], b16x32[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b16x8[i] = b8x16[i] = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) b32x8[i] = b8x32[i] = 0xffffffffu;
+    b32x16[0] = b32x16[1] = b16x32[0] = b16x32[1] = 0xffffffffu;
+    uint32_t bcross[12];  // keys raw << 14 | idx of the cross-quadrant PUs, positions 4Q..4Q+3 of every item
+#pragma unroll
+    for (int i = 0; i < 12; i++) bcross[i] = 0xffffffffu;
+    uint32_t q5_raw = 0xffffffffu, q5_idx = 0;  // PU 32x16[5]: wave-uniform state of the recurrence (wave 0 only)
+
+    const uint32_t himask = 0xffff0000u;
+    const int n_items = n_xg * sh;
+    const int n_iter = (n_items + 63) >> 6;
+
+    for (int it = 0; it < n_iter; it++) {
+        int pg = it * 64 + lane;
+        const bool lane_valid = pg < n_items;
+        if (!lane_valid) pg = 0;
+        const int y = pg / n_xg;
+        const int xg = pg - y * n_xg;
+
+        // per-position raster index; positions outside the search area get idx = ~0 so that every key
+        // OR-ed with it is 0xffffffff and can never win (at least one position is always valid)
+        uint32_t idx[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int x = 16 * xg + i;
+            idx[i] = (lane_valid && x < sw) ? (uint32_t)(y * 128 + x) : 0xffffffffu;
+        }
+
+        uint32_t s16lo[4][4], s16hi[4][4];  // [zz][q] packed u16 16x16 sums
+        uint64_t hrow[2][4];     // [part][q] 16x8 sums of the left 16x16 of the current row of 16x16s, kept for 32x8
+        uint64_t hcol[2][2][4];  // [C][side][q] 8x16 sums of the upper row of 16x16s, kept for 8x32
+
+        const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
+
+#pragma unroll
+        for (int zz = 0; zz < 4; zz++) {
+            const int C = zz & 1, R = zz >> 1;
+            uint64_t acc[4][4];
+
+#pragma unroll
+            for (int r8 = 0; r8 < 8; r8++) {
+                const uint8_t* p = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
+                const uint4 A = *reinterpret_cast<const uint4*>(p);
+                const uint4 B = *reinterpret_cast<const uint4*>(p + 16);
+                const uint32_t W[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+                const uint32_t* srow = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
+                uint32_t S[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) S[h] = srow[h];  // uniform address, read-only -> s_load_dwordx4
+                const int krow = (r8 >> 2) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+                        const int k = krow + (h >> 1);
+                        const bool first = ((r8 & 3) == 0) && ((h & 1) == 0);  // first touch of acc[k][q]
+                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(W[q + h], W[q + h + 1]), S[h],
+                                                                    first ? 0ull : acc[k][q]);
+                    }
+            }
+
+            // 8x8 PUs of this 16x16
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) best8[4 * zz + k] = track4(best8[4 * zz + k], acc[k][q], &idx[4 * q], himask);
+
+            // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t lo = (uint32_t)acc[0][q] + (uint32_t)acc[1][q] + (uint32_t)acc[2][q] + (uint32_t)acc[3][q];
+                const uint32_t hi = (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32) +
+                                    (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32);
+                best16[zz] = track4(best16[zz], pack64(lo, hi), &idx[4 * q], himask);
+                s16lo[zz][q] = lo;
+                s16hi[zz][q] = hi;
+            }
+            // 16x8 (top / bottom halves) and 8x16 (left / right halves) of this 16x16: packed sums of two 8x8 (<= 16320)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t top = pack64((uint32_t)acc[0][q] + (uint32_t)acc[1][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32));
+                const uint64_t bot = pack64((uint32_t)acc[2][q] + (uint32_t)acc[3][q], (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
+                const uint64_t lef = pack64((uint32_t)acc[0][q] + (uint32_t)acc[2][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[2][q] >> 32));
+                const uint64_t rig = pack64((uint32_t)acc[1][q] + (uint32_t)acc[3][q], (uint32_t)(acc[1][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
+                b16x8[2 * zz + 0] = track4(b16x8[2 * zz + 0], top, &idx[4 * q], himask);
+                b16x8[2 * zz + 1] = track4(b16x8[2 * zz + 1], bot, &idx[4 * q], himask);
+                b8x16[2 * zz + 0] = track4(b8x16[2 * zz + 0], lef, &idx[4 * q], himask);
+                b8x16[2 * zz + 1] = track4(b8x16[2 * zz + 1], rig, &idx[4 * q], himask);
+                // 32x8 = two 16x8 side by side (zz pairs (0,1), (2,3)); 8x32 = two 8x16 on top of each other (pairs (0,2), (1,3)); <= 32640
+                if (C == 0) { hrow[0][q] = top; hrow[1][q] = bot; }
+                else {
+                    const uint64_t a0 = hrow[0][q], a1 = hrow[1][q];
+                    b32x8[2 * R + 0] = track4(b32x8[2 * R + 0], pack64((uint32_t)a0 + (uint32_t)top, (uint32_t)(a0 >> 32) + (uint32_t)(top >> 32)),
+                                              &idx[4 * q], himask);
+                    b32x8[2 * R + 1] = track4(b32x8[2 * R + 1], pack64((uint32_t)a1 + (uint32_t)bot, (uint32_t)(a1 >> 32) + (uint32_t)(bot >> 32)),
+                                              &idx[4 * q], himask);
+                }
+                if (R == 0) { hcol[C][0][q] = lef; hcol[C][1][q] = rig; }
+                else {
+                    const uint64_t a0 = hcol[C][0][q], a1 = hcol[C][1][q];
+                    b8x32[2 * C + 0] = track4(b8x32[2 * C + 0], pack64((uint32_t)a0 + (uint32_t)lef, (uint32_t)(a0 >> 32) + (uint32_t)(lef >> 32)),
+                                              &idx[4 * q], himask);
+                    b8x32[2 * C + 1] = track4(b8x32[2 * C + 1], pack64((uint32_t)a1 + (uint32_t)rig, (uint32_t)(a1 >> 32) + (uint32_t)(rig >> 32)),
+                                              &idx[4 * q], himask);
+                }
+            }
+        }
+        // 32x16 (top / bottom) and 16x32 (left / right) of the quadrant: packed sums of two 16x16 (<= 65280 still fits 16 bits)
+        uint32_t r32x16lo[2][4], r32x16hi[2][4], r16x32lo[2][4], r16x32hi[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                r32x16lo[k][q] = s16lo[2 * k][q] + s16lo[2 * k + 1][q];
+                r32x16hi[k][q] = s16hi[2 * k][q] + s16hi[2 * k + 1][q];
+                r16x32lo[k][q] = s16lo[k][q] + s16lo[k + 2][q];
+                r16x32hi[k][q] = s16hi[k][q] + s16hi[k + 2][q];
+                if (!(Q == 2 && k == 1))  // 32x16[5] follows the stale-variable recurrence instead (wave-uniform branch)
+                    b32x16[k] = track4(b32x16[k], pack64(r32x16lo[k][q], r32x16hi[k][q]), &idx[4 * q], himask);
+                b16x32[k] = track4(b16x32[k], pack64(r16x32lo[k][q], r16x32hi[k][q]), &idx[4 * q], himask);
+            }
+        }
+
+        // 32x32 = sum of the four 16x16: pairs are added packed (<= 2*32640 fits u16), then widened
+        uint32_t s32acc[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t a_lo = s16lo[0][q] + s16lo[1][q], b_lo = s16lo[2][q] + s16lo[3][q];
+            const uint32_t a_hi = s16hi[0][q] + s16hi[1][q], b_hi = s16hi[2][q] + s16hi[3][q];
+            s32acc[4 * q + 0] = (a_lo & 0xffffu) + (b_lo & 0xffffu);
+            s32acc[4 * q + 1] = (a_lo >> 16) + (b_lo >> 16);
+            s32acc[4 * q + 2] = (a_hi & 0xffffu) + (b_hi & 0xffffu);
+            s32acc[4 * q + 3] = (a_hi >> 16) + (b_hi >> 16);
+        }
+
+        // 32x32 PU of this quadrant: key = raw << 14 | idx  (raw <= 130560 < 2^17)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            uint32_t k0 = (s32acc[i] << 14) | idx[i];
+            uint32_t k1 = (s32acc[i + 1] << 14) | idx[i + 1];
+            best32 = min3u(best32, k0, k1);
+        }
+
+        // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
+        __syncthreads();  // previous iteration's readers are done
+        {
+            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; q++) dst[q] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
+        }
+        __syncthreads();
+        const int xbase = 16 * xg + 4 * Q;
+        const uint32_t ibase = (uint32_t)(y * 128 + xbase);
+        uint32_t cidx[4];  // idx of positions 4Q..4Q+3 (idx[] is indexed statically, so rebuilt from Q)
+#pragma unroll
+        for (int j = 0; j < 4; j++) cidx[j] = (lane_valid && xbase + j < sw) ? ibase + j : 0xffffffffu;
+        {
+            uint4 v[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
+            const uint32_t q0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, q1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+            const uint32_t q2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, q3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t top = q0[j] + q1[j], bot = q2[j] + q3[j], lef = q0[j] + q2[j], rig = q1[j] + q3[j], all = top + bot;
+                // strict '<', positions visited in raster order per lane; positions outside the area never win
+                const bool better = (all < best64_raw) && cidx[j] != 0xffffffffu;
+                best64_raw = better ? all : best64_raw;
+                best64_idx = better ? cidx[j] : best64_idx;
+                bcross[0] = min(bcross[0], (top << 14) | cidx[j]);   // 64x32[0]   (<= 261120 < 2^18)
+                bcross[1] = min(bcross[1], (bot << 14) | cidx[j]);   // 64x32[1]
+                bcross[2] = min(bcross[2], (lef << 14) | cidx[j]);   // 32x64[0]
+                bcross[3] = min(bcross[3], (rig << 14) | cidx[j]);   // 32x64[1]
+                qa[lane * 16 + 4 * Q + j] = bot;                     // 64x32[1] per position, for the 32x16[5] recurrence
+            }
+        }
+        // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
+        __syncthreads();
+        {
+            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            dst[0] = make_uint4(r32x16lo[0][0], r32x16hi[0][0], r32x16lo[0][1], r32x16hi[0][1]);
+            dst[1] = make_uint4(r32x16lo[0][2], r32x16hi[0][2], r32x16lo[0][3], r32x16hi[0][3]);
+            dst[2] = make_uint4(r32x16lo[1][0], r32x16hi[1][0], r32x16lo[1][1], r32x16hi[1][1]);
+            dst[3] = make_uint4(r32x16lo[1][2], r32x16hi[1][2], r32x16lo[1][3], r32x16hi[1][3]);
+            if (Q == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<uint4*>(qv + lane * 16 + 4 * q) =
+                        make_uint4(r32x16lo[1][q] & 0xffffu, r32x16lo[1][q] >> 16, r32x16hi[1][q] & 0xffffu, r32x16hi[1][q] >> 16);
+            }
+        }
+        __syncthreads();
+        {
+            // positions 4Q..4Q+3 = dwords (2Q, 2Q+1) of each PU's 8-dword run: [w][R] at xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q
+            uint32_t pr[4][2][4];
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int R = 0; R < 2; R++) {
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q);
+                    pr[w][R][0] = t.x & 0xffffu; pr[w][R][1] = t.x >> 16; pr[w][R][2] = t.y & 0xffffu; pr[w][R][3] = t.y >> 16;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bcross[4] = min(bcross[4], ((pr[0][0][j] + pr[1][0][j]) << 14) | cidx[j]);  // 64x16[0] = 32x16[0] + 32x16[2]
+                bcross[5] = min(bcross[5], ((pr[0][1][j] + pr[1][1][j]) << 14) | cidx[j]);  // 64x16[1] = 32x16[1] + 32x16[3]
+                bcross[6] = min(bcross[6], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
+                bcross[7] = min(bcross[7], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
+            }
+        }
+        // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
+        __syncthreads();
+        {
+            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            dst[0] = make_uint4(r16x32lo[0][0], r16x32hi[0][0], r16x32lo[0][1], r16x32hi[0][1]);
+            dst[1] = make_uint4(r16x32lo[0][2], r16x32hi[0][2], r16x32lo[0][3], r16x32hi[0][3]);
+            dst[2] = make_uint4(r16x32lo[1][0], r16x32hi[1][0], r16x32lo[1][1], r16x32hi[1][1]);
+            dst[3] = make_uint4(r16x32lo[1][2], r16x32hi[1][2], r16x32lo[1][3], r16x32hi[1][3]);
+        }
+        __syncthreads();
+        {
+            uint32_t pc[4][2][4];
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int C = 0; C < 2; C++) {
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + (w * 64 + lane) * 16 + 8 * C + 2 * Q);
+                    pc[w][C][0] = t.x & 0xffffu; pc[w][C][1] = t.x >> 16; pc[w][C][2] = t.y & 0xffffu; pc[w][C][3] = t.y >> 16;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bcross[8] = min(bcross[8], ((pc[0][0][j] + pc[2][0][j]) << 14) | cidx[j]);    // 16x64[0] = 16x32[0] + 16x32[4]
+                bcross[9] = min(bcross[9], ((pc[0][1][j] + pc[2][1][j]) << 14) | cidx[j]);    // 16x64[1] = 16x32[1] + 16x32[5]
+                bcross[10] = min(bcross[10], ((pc[1][0][j] + pc[3][0][j]) << 14) | cidx[j]);  // 16x64[2] = 16x32[2] + 16x32[6]
+                bcross[11] = min(bcross[11], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
+            }
+        }
+        if (Q == 0) {
+            // 32x16[5] (:343-347): in raster order, "if (sad of 64x32[1] < best) best = sad of 32x16[5]".  The items of an
+            // iteration are consecutive in raster order (lane = item, 16 positions each), so the rank inside the chunk is
+            // lane * 16 + position.  Every update lowers the best (32x16[5] is part of 64x32[1]), so the loop is short.
+            uint32_t av[16], vv[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(qa + lane * 16 + 4 * q), v4 = *reinterpret_cast<const uint4*>(qv + lane * 16 + 4 * q);
+                av[4 * q] = a4.x; av[4 * q + 1] = a4.y; av[4 * q + 2] = a4.z; av[4 * q + 3] = a4.w;
+                vv[4 * q] = v4.x; vv[4 * q + 1] = v4.y; vv[4 * q + 2] = v4.z; vv[4 * q + 3] = v4.w;
+            }
+            int last = -1;  // rank of the last update inside this chunk
+            for (;;) {
+                uint32_t cand = 0xffffffffu;  // (rank << 16 | new best) of this lane's first qualifying position
+#pragma unroll
+                for (int i = 15; i >= 0; i--) {
+                    const int rank = lane * 16 + i;
+                    const bool ok = idx[i] != 0xffffffffu && rank > last && av[i] < q5_raw;
+                    cand = ok ? (((uint32_t)rank << 16) | vv[i]) : cand;
+                }
+                cand = wave_min_u32(cand);
+                if (cand == 0xffffffffu) break;  // wave-uniform
+                last = (int)(cand >> 16);
+                q5_raw = cand & 0xffffu;
+                // raster index of that position: the lane that owns it broadcasts its idx
+                const int owner = last >> 4, pos = last & 15;
+                uint32_t myidx = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) myidx = (pos == i) ? idx[i] : myidx;
+                q5_idx = (uint32_t)__shfl((int)myidx, owner);
+            }
+        }
+    }
+
+    // ---- reduce across the wave and publish ----
+    uint32_t* osad = out_sad + (size_t)209 * sbi;
+    uint32_t* omv = out_mv + (size_t)209 * sbi;
+
+    uint32_t red[21];
+#pragma unroll
+    for (int i = 0; i < 16; i++) red[i] = wave_min_u32(best8[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) red[16 + i] = wave_min_u32(best16[i]);
+    red[20] = wave_min_u32(best32);
+    const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
+    uint32_t rr[28];  // in-quadrant rectangles: 16x8[8] 8x16[8] 32x8[4] 8x32[4] 32x16[2] 16x32[2]
+#pragma unroll
+    for (int i = 0; i < 8; i++) { rr[i] = wave_min_u32(b16x8[i]); rr[8 + i] = wave_min_u32(b8x16[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { rr[16 + i] = wave_min_u32(b32x8[i]); rr[20 + i] = wave_min_u32(b8x32[i]); }
+    rr[24] = wave_min_u32(b32x16[0]); rr[25] = wave_min_u32(b32x16[1]); rr[26] = wave_min_u32(b16x32[0]); rr[27] = wave_min_u32(b16x32[1]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) bcross[i] = wave_min_u32(bcross[i]);
+
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) {
+            const uint32_t key = red[i];
+            uint32_t raw, id;
+            int pu;
+            if (i < 16) { raw = key >> 16; id = key & 0x3fffu; pu = 21 + 16 * Q + i; }
+            else if (i < 20) { raw = key >> 16; id = key & 0x3fffu; pu = 5 + 4 * Q + (i - 16); }
+            else { raw = key >> 14; id = key & 0x3fffu; pu = 1 + Q; }
+            osad[pu] = 2u * raw;
+            omv[pu] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
+        }
+#pragma unroll
+        for (int i = 0; i < 28; i++) {
+            // ME-buffer index of the rectangle (Codec/EbMotionEstimationContext.h:132-261; index algebra in DESIGN 3.1)
+            int pu;
+            if (i < 8) pu = 95 + 8 * Q + i;                    // 16x8[2 * z16 + part], z16 = 4Q + zz
+            else if (i < 16) pu = 137 + 8 * Q + (i - 8);       // 8x16[2 * z16 + side]
+            else if (i < 20) pu = 169 + 4 * Q + (i - 16);      // 32x8[4Q + 2R + part]
+            else if (i < 24) pu = 185 + 4 * Q + (i - 20);      // 8x32[4Q + 2C + side]
+            else if (i < 26) pu = 87 + 2 * Q + (i - 24);       // 32x16[2Q + R]
+            else pu = 129 + 2 * Q + (i - 26);                  // 16x32[2Q + C]
+            if (pu == 92) continue;                            // 32x16[5]: written by wave 0 below
+            const uint32_t key = rr[i];
+            osad[pu] = 2u * (key >> 16);
+            omv[pu] = mv_word(xo + (int)(key & 127u), yo + (int)((key >> 7) & 127u));
+        }
+        atomicMin(best64_lds, k64);
+#pragma unroll
+        for (int i = 0; i < 12; i++) atomicMin(&cross_lds[i], bcross[i]);
+        if (Q == 0) {
+            osad[92] = 2u * q5_raw;
+            omv[92] = mv_word(xo + (int)(q5_idx & 127u), yo + (int)(q5_idx >> 7));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long k = *best64_lds;
+        const uint32_t raw = (uint32_t)(k >> 32), id = (uint32_t)k;
+        osad[0] = 2u * raw;
+        omv[0] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
+    }
+    if (tid < 12) {
+        const int pu = tid < 2 ? 85 + tid : (tid < 4 ? 127 + (tid - 2) : (tid < 8 ? 201 + (tid - 4) : 205 + (tid - 8)));
+        const uint32_t key = cross_lds[tid];
+        osad[pu] = 2u * (key >> 14);
+        omv[pu] = mv_word(xo + (int)(key & 127u), yo + (int)((key >> 7) & 127u));
+    }
+}

@@ -61,6 +61,11 @@ hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int 
                             int w, int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff,
                             int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s);
 
+__global__ void fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
+                                  uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
+                                  uint32_t* __restrict__ out_mv);
+size_t fullpel209_lds_bytes(uint32_t max_sh);
+
 __global__ void me_search_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P, uint32_t list_index,
                                  const svthip_sb_origin* __restrict__ sbs, const uint32_t* __restrict__ l0_best_mv64,
                                  uint32_t l0_mv_stride, svthip_fullpel_desc* __restrict__ out_desc, int16_t* __restrict__ out_center,

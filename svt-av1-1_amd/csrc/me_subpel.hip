@@ -362,7 +362,10 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // role of this wave: 0 = 64x64, 1 = 32x32s, 2 = 16x16s, 3 = 8x8s.  The roles differ in work (the 8x8 wave fills twice the
+    // tile samples of the 64x64 wave) and wave k of every workgroup lands on SIMD k, so the assignment rotates with the
+    // workgroup index to even out the four SIMDs of a CU.
+    const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);
     const int32_t* d = desc + 6 * blockIdx.x;
     const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
 
@@ -519,7 +522,10 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t bisad[85];  // indexed by ME-buffer PU index
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // role of this wave: 0 = 64x64, 1 = 32x32s, 2 = 16x16s, 3 = 8x8s.  The roles differ in work (the 8x8 wave fills twice the
+    // tile samples of the 64x64 wave) and wave k of every workgroup lands on SIMD k, so the assignment rotates with the
+    // workgroup index to even out the four SIMDs of a CU.
+    const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);
     const size_t sb = blockIdx.x;
     const uint32_t* s0 = sad0 + 85 * sb;
     const uint32_t* m0 = mv0 + 85 * sb;

@@ -39,6 +39,7 @@ struct svthip_ctx {
     size_t scratch_bytes[6];
     int max_dyn_lds_set;
     int max_dyn_lds_search;
+    int max_dyn_lds_209;
 };
 
 namespace {
@@ -210,6 +211,32 @@ int32_t svthip_quantize_b_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff, con
     const uint32_t waves = n_tu < 8192u ? n_tu : 8192u;  // grid-stride beyond 2048 workgroups
     hipLaunchKernelGGL(svthip::quantize_b_batch_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, d_coeff, d_desc, n_tu, d_qparams,
                        d_iscan, d_qcoeff, d_dqcoeff, d_eob);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
+int32_t svthip_me_fullpel_search209_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                        uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb,
+                                        uint32_t max_search_area_width, uint32_t max_search_area_height, uint32_t* d_best_sad,
+                                        uint32_t* d_best_mv, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (!d_src_plane || !d_ref_plane || !d_desc || !d_best_sad || !d_best_mv) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127 (%s%d)", "got ",
+                    (int)(max_search_area_width > max_search_area_height ? max_search_area_width : max_search_area_height));
+    if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
+    const size_t lds = svthip::fullpel209_lds_bytes(max_search_area_height);
+    if ((int)lds > ctx->max_dyn_lds_209) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::fullpel209_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        ctx->max_dyn_lds_209 = (int)lds;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::fullpel209_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
+                       reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv);
     HIP_TRY(hipGetLastError());
     return SVTHIP_OK;
 }

@@ -79,6 +79,9 @@ def lib() -> C.CDLL:
     L.svthip_motion_estimate_picture_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p]
+    L.svthip_me_fullpel_search209_dev.restype = C.c_int32
+    L.svthip_me_fullpel_search209_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.svthip_motion_estimate_batch_dev.restype = C.c_int32
     L.svthip_motion_estimate_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                                    C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -224,6 +227,13 @@ def _motion_estimate_batch_dev(self, d_pool, curs, refs0, refs1, params, d_sb, n
 Context.motion_estimate_batch_dev = _motion_estimate_batch_dev
 
 
+def _fullpel_search209_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv, stream=None):
+    """209-PU full-pel search (squares + rectangles); d_sad / d_mv: [n_sb][209] uint32 device arrays."""
+    _check(lib().svthip_me_fullpel_search209_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv,
+                                                 stream))
+
+
+Context.fullpel_search209_dev = _fullpel_search209_dev
 Context.hme_search_center_dev = _hme_search_center_dev
 Context.hme_search_center_batch_dev = _hme_search_center_batch_dev
 Context.integer_search_batch_dev = _integer_search_batch_dev

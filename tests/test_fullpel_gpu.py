@@ -106,3 +106,42 @@ def test_bad_arguments_fail_loudly(hip_ctx):
     bad[0, 1] = cur.full.size  # window outside the plane
     with pytest.raises(svtav1_hip.SvtHipError):
         hip_ctx.fullpel_search(cur.full, ref.full, bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 209-PU mode (row a9)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(192, 136, "synth", 64, 64), (192, 136, "random", 23, 9), (136, 128, "flat", 16, 16),
+                                  (192, 136, "pan", 127, 40), (192, 136, "extreme", 33, 33), (328, 200, "synth", 64, 64),
+                                  (192, 136, "synth", 127, 127), (192, 136, "pan", 1, 1)])
+def test_fullpel_209pu_matches_oracle(hip_ctx, oracle, case):
+    """Squares and rectangles (incl. PU 92's stale-variable recurrence) vs the reference-pinned oracle, bit-exact."""
+    import torch
+    from svtav1_hip import synth
+    w, h, kind, sw, sh = case
+    rng = np.random.default_rng(sw * 100 + sh)
+    if kind == "synth":
+        f = [synth.synth_luma(w, h, 3), synth.synth_luma(w, h, 0)]
+    elif kind == "pan":
+        big = synth.synth_luma(w + 64, h + 64, 0); f = [big[20:20 + h, 30:30 + w], big[17:17 + h, 21:21 + w]]
+    elif kind == "flat":
+        f = [np.full((h, w), 77, np.uint8), np.full((h, w), 77, np.uint8)]
+    elif kind == "extreme":
+        f = [rng.choice([0, 255], (h, w)).astype(np.uint8), rng.choice([0, 255], (h, w)).astype(np.uint8)]
+    else:
+        f = [rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h, w), dtype=np.uint8)]
+    cur, ref = synth.PaPicture(np.ascontiguousarray(f[0])), synth.PaPicture(np.ascontiguousarray(f[1]))
+    nx, ny = cur.sb_grid()
+    centers = rng.integers(-20, 21, size=(nx * ny, 2))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, centers, sw, sh)
+    s_o, m_o = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    dev = torch.device("cuda:0")
+    d_src, d_ref, d_desc = torch.from_numpy(cur.full).to(dev), torch.from_numpy(ref.full).to(dev), torch.from_numpy(desc).to(dev)
+    n = desc.shape[0]
+    d_sad = torch.full((n, 209), -1, dtype=torch.int32, device=dev); d_mv = torch.full((n, 209), -1, dtype=torch.int32, device=dev)
+    hip_ctx.fullpel_search209_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), n, int(desc[:, 4].max()),
+                                  int(desc[:, 5].max()), d_sad.data_ptr(), d_mv.data_ptr())
+    hip_ctx.synchronize()
+    s_h, m_h = d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
+    bad = np.argwhere((s_h != s_o) | (m_h != m_o))
+    assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}: hip {s_h[tuple(bad[0])]}/{m_h[tuple(bad[0])]:#x} oracle {s_o[tuple(bad[0])]}/{m_o[tuple(bad[0])]:#x}; PUs {sorted(set(bad[:, 1]))[:20]}"

@@ -70,3 +70,38 @@ def test_sad_loop_kernel(oracle, reference, shape):
         if sw >= 8:
             c = reference.sad_loop("SadLoopKernel_SSE4_1_INTRIN", src, 0, 64, ref, ro, 256, bh, bw, 256, sw, sh)
             assert a == c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 209-PU mode (row a9): squares + rectangular PUs, incl. the stale-variable update of 32x16[5]
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(192, 136, "synth", 64, 64), (192, 136, "random", 23, 9), (136, 128, "flat", 16, 16),
+                                  (192, 136, "pan", 127, 40), (192, 136, "extreme", 33, 33)])
+def test_fullpel_209pu_matches_reference(oracle, case):
+    from oracle.binding import ReferenceME
+    if not ReferenceME.available():
+        pytest.skip("oracle/_ref/libsvtref_me.so not built")
+    import svtav1_hip
+    from svtav1_hip import synth
+    w, h, kind, sw, sh = case
+    rng = np.random.default_rng(sw * 100 + sh)
+    if kind == "synth":
+        f = [synth.synth_luma(w, h, 3), synth.synth_luma(w, h, 0)]
+    elif kind == "pan":
+        big = synth.synth_luma(w + 64, h + 64, 0); f = [big[20:20 + h, 30:30 + w], big[17:17 + h, 21:21 + w]]
+    elif kind == "flat":
+        f = [np.full((h, w), 77, np.uint8), np.full((h, w), 77, np.uint8)]        # all SADs zero: every update is a tie
+    elif kind == "extreme":
+        f = [rng.choice([0, 255], (h, w)).astype(np.uint8), rng.choice([0, 255], (h, w)).astype(np.uint8)]
+    else:
+        f = [rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h, w), dtype=np.uint8)]
+    cur, ref = synth.PaPicture(np.ascontiguousarray(f[0])), synth.PaPicture(np.ascontiguousarray(f[1]))
+    nx, ny = cur.sb_grid()
+    centers = rng.integers(-20, 21, size=(nx * ny, 2))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, centers, sw, sh)
+    s_o, m_o = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    s_r, m_r = ReferenceME().fullpel_search209_batch(cur.full, ref.full, desc)
+    assert np.array_equal(s_o, s_r), np.argwhere(s_o != s_r)[:5]
+    assert np.array_equal(m_o, m_r), np.argwhere(m_o != m_r)[:5]
+    s85, m85 = oracle.fullpel_search_batch(cur.full, ref.full, desc)          # the squares agree with the 85-PU mode
+    assert np.array_equal(s_o[:, :85], s85) and np.array_equal(m_o[:, :85], m85)
