@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t mv_word(int x, int y)
 }
 
 
-constexpr int kFp209Fixed = 16384 + 8192 + 128;  // exchange buffer, (64x32[1], 32x16[5]) pairs, cross-quadrant results
+constexpr int kFp209Fixed = 16384 + 8192 + 1024;  // exchange buffer, (64x32[1], 32x16[5]) pairs, 64x64 result + best key per PU
 
 // d: the superblock's descriptor (6 int32: src_offset, ref_offset, x/y search origin, search width/height), any address space;
 // smem: kFp209Fixed + (sh + 63) * SVTHIP_FULLPEL_LDS_PITCH bytes of workgroup LDS, 16-byte aligned.
@@ -77,12 +77,15 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                                              uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv, uint8_t* smem)
 {
     // LDS layout: [0,16K) exchange buffer, [16K,24K) per-position 64x32[1] / 32x16[5] SADs of the current iteration,
-    // [24K,24K+128) cross-quadrant results, then the window.
+    // [24K,24K+1K) 64x64 result and one best key per PU, then the window.
     uint32_t* xch = reinterpret_cast<uint32_t*>(smem);
     uint32_t* qa = reinterpret_cast<uint32_t*>(smem + 16384);          // [64 lanes][16 positions] 64x32[1]
     uint32_t* qv = reinterpret_cast<uint32_t*>(smem + 16384 + 4096);   // [64 lanes][16 positions] 32x16[5]
     unsigned long long* best64_lds = reinterpret_cast<unsigned long long*>(smem + 24576);
-    uint32_t* cross_lds = reinterpret_cast<uint32_t*>(smem + 24576 + 16);  // 12 keys: 64x32[2] 32x64[2] 64x16[4] 16x64[4]
+    // best (sad << k | raster idx) key of every PU.  Per-lane trackers are reduced over the wave and merged here with
+    // ds_min_u32 as soon as an iteration has produced them: kept in registers across the whole loop (as in the 85-PU kernel) the
+    // 61 trackers of this mode pushed the kernel to 256 VGPRs + scratch spills, which made it 3x slower than the extra VALU work
+    uint32_t* pu_key = reinterpret_cast<uint32_t*>(smem + 24576 + 16);  // [209]
     uint8_t* win = smem + kFp209Fixed;
 
     const int tid = threadIdx.x;
@@ -120,7 +123,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             reinterpret_cast<uint32_t*>(win)[i] = v;
         }
         if (tid == 0) *best64_lds = ~0ull;
-        if (tid < 12) cross_lds[tid] = 0xffffffffu;
+        if (tid < 209) pu_key[tid] = 0xffffffffu;
     }
     __syncthreads();
 
@@ -128,25 +131,21 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     const uint32_t* src4 = reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)(32 * Qy) * src_stride + 32 * Qx);
     const int sstride4 = src_stride >> 2;
 
-    uint32_t best8[16], best16[4], best32 = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < 16; i++) best8[i] = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < 4; i++) best16[i] = 0xffffffffu;
     uint32_t best64_raw = 0xffffffffu, best64_idx = 0;
-    // rectangles inside the quadrant: 16x8 / 8x16 [2 * zz + part], 32x8 [2 * R + part], 8x32 [2 * C + side], 32x16 [R], 16x32 [C]
-    uint32_t b16x8[8], b8x16[8], b32x8[4], b8x32[4], b32x16[2], b16x32[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) b16x8[i] = b8x16[i] = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < 4; i++) b32x8[i] = b8x32[i] = 0xffffffffu;
-    b32x16[0] = b32x16[1] = b16x32[0] = b16x32[1] = 0xffffffffu;
-    uint32_t bcross[12];  // keys raw << 14 | idx of the cross-quadrant PUs, positions 4Q..4Q+3 of every item
-#pragma unroll
-    for (int i = 0; i < 12; i++) bcross[i] = 0xffffffffu;
     uint32_t q5_raw = 0xffffffffu, q5_idx = 0;  // PU 32x16[5]: wave-uniform state of the recurrence (wave 0 only)
 
     const uint32_t himask = 0xffff0000u;
+    auto flush = [&](int pu, uint32_t key) {  // wave-wide minimum of a tracker -> the PU's LDS key
+        // four DPP steps leave every row of 16 lanes with its minimum, four v_readlane + scalar min combine the rows: 8 VALU
+        // instructions and no LDS round trips (61 of these per iteration: ds_bpermute shuffles cost +40 % kernel time)
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x141, 0xf, 0xf, false));  // row_half_mirror
+        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x140, 0xf, 0xf, false));  // row_mirror
+        const uint32_t m = min(min((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16)),
+                               min((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48)));
+        if (lane == 0) atomicMin(&pu_key[pu], m);
+    };
     const int n_items = n_xg * sh;
     const int n_iter = (n_items + 63) >> 6;
 
@@ -182,7 +181,15 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 const uint8_t* p = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
                 const uint4 A = *reinterpret_cast<const uint4*>(p);
                 const uint4 B = *reinterpret_cast<const uint4*>(p + 16);
-                const uint32_t W[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
+                // window dword pairs (W[k], W[k+1]), k = 0..6: the even ones are the loaded register pairs, the odd ones are formed
+                // with one v_pk_mov_b32 each (hi of one pair, lo of the next).  Left to the compiler they cost two v_mov each
+                // and, under register pressure (209-PU kernel), a round trip through scratch memory.
+                const uint64_t E0 = pack64(A.x, A.y), E1 = pack64(A.z, A.w), E2 = pack64(B.x, B.y), E3 = pack64(B.z, B.w);
+                uint64_t O0, O1, O2;
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O0) : "v"(E0), "v"(E1));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O1) : "v"(E1), "v"(E2));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O2) : "v"(E2), "v"(E3));
+                const uint64_t PR[7] = {E0, O0, E1, O1, E2, O2, E3};
                 const uint32_t* srow = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
                 uint32_t S[4];
 #pragma unroll
@@ -194,16 +201,18 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                     for (int h = 0; h < 4; h++) {
                         const int k = krow + (h >> 1);
                         const bool first = ((r8 & 3) == 0) && ((h & 1) == 0);  // first touch of acc[k][q]
-                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(W[q + h], W[q + h + 1]), S[h],
-                                                                    first ? 0ull : acc[k][q]);
+                        acc[k][q] = __builtin_amdgcn_qsad_pk_u16_u8(PR[q + h], S[h], first ? 0ull : acc[k][q]);
                     }
             }
 
             // 8x8 PUs of this 16x16
+            uint32_t k8[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, k16 = 0xffffffffu;
+            uint32_t k16x8[2] = {0xffffffffu, 0xffffffffu}, k8x16[2] = {0xffffffffu, 0xffffffffu};
+            uint32_t k32x8[2] = {0xffffffffu, 0xffffffffu}, k8x32[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) best8[4 * zz + k] = track4(best8[4 * zz + k], acc[k][q], &idx[4 * q], himask);
+                for (int q = 0; q < 4; q++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
 
             // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
 #pragma unroll
@@ -211,7 +220,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 const uint32_t lo = (uint32_t)acc[0][q] + (uint32_t)acc[1][q] + (uint32_t)acc[2][q] + (uint32_t)acc[3][q];
                 const uint32_t hi = (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32) +
                                     (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32);
-                best16[zz] = track4(best16[zz], pack64(lo, hi), &idx[4 * q], himask);
+                k16 = track4(k16, pack64(lo, hi), &idx[4 * q], himask);
                 s16lo[zz][q] = lo;
                 s16hi[zz][q] = hi;
             }
@@ -222,31 +231,41 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 const uint64_t bot = pack64((uint32_t)acc[2][q] + (uint32_t)acc[3][q], (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
                 const uint64_t lef = pack64((uint32_t)acc[0][q] + (uint32_t)acc[2][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[2][q] >> 32));
                 const uint64_t rig = pack64((uint32_t)acc[1][q] + (uint32_t)acc[3][q], (uint32_t)(acc[1][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
-                b16x8[2 * zz + 0] = track4(b16x8[2 * zz + 0], top, &idx[4 * q], himask);
-                b16x8[2 * zz + 1] = track4(b16x8[2 * zz + 1], bot, &idx[4 * q], himask);
-                b8x16[2 * zz + 0] = track4(b8x16[2 * zz + 0], lef, &idx[4 * q], himask);
-                b8x16[2 * zz + 1] = track4(b8x16[2 * zz + 1], rig, &idx[4 * q], himask);
+                k16x8[0] = track4(k16x8[0], top, &idx[4 * q], himask);
+                k16x8[1] = track4(k16x8[1], bot, &idx[4 * q], himask);
+                k8x16[0] = track4(k8x16[0], lef, &idx[4 * q], himask);
+                k8x16[1] = track4(k8x16[1], rig, &idx[4 * q], himask);
                 // 32x8 = two 16x8 side by side (zz pairs (0,1), (2,3)); 8x32 = two 8x16 on top of each other (pairs (0,2), (1,3)); <= 32640
                 if (C == 0) { hrow[0][q] = top; hrow[1][q] = bot; }
                 else {
                     const uint64_t a0 = hrow[0][q], a1 = hrow[1][q];
-                    b32x8[2 * R + 0] = track4(b32x8[2 * R + 0], pack64((uint32_t)a0 + (uint32_t)top, (uint32_t)(a0 >> 32) + (uint32_t)(top >> 32)),
+                    k32x8[0] = track4(k32x8[0], pack64((uint32_t)a0 + (uint32_t)top, (uint32_t)(a0 >> 32) + (uint32_t)(top >> 32)),
                                               &idx[4 * q], himask);
-                    b32x8[2 * R + 1] = track4(b32x8[2 * R + 1], pack64((uint32_t)a1 + (uint32_t)bot, (uint32_t)(a1 >> 32) + (uint32_t)(bot >> 32)),
+                    k32x8[1] = track4(k32x8[1], pack64((uint32_t)a1 + (uint32_t)bot, (uint32_t)(a1 >> 32) + (uint32_t)(bot >> 32)),
                                               &idx[4 * q], himask);
                 }
                 if (R == 0) { hcol[C][0][q] = lef; hcol[C][1][q] = rig; }
                 else {
                     const uint64_t a0 = hcol[C][0][q], a1 = hcol[C][1][q];
-                    b8x32[2 * C + 0] = track4(b8x32[2 * C + 0], pack64((uint32_t)a0 + (uint32_t)lef, (uint32_t)(a0 >> 32) + (uint32_t)(lef >> 32)),
+                    k8x32[0] = track4(k8x32[0], pack64((uint32_t)a0 + (uint32_t)lef, (uint32_t)(a0 >> 32) + (uint32_t)(lef >> 32)),
                                               &idx[4 * q], himask);
-                    b8x32[2 * C + 1] = track4(b8x32[2 * C + 1], pack64((uint32_t)a1 + (uint32_t)rig, (uint32_t)(a1 >> 32) + (uint32_t)(rig >> 32)),
+                    k8x32[1] = track4(k8x32[1], pack64((uint32_t)a1 + (uint32_t)rig, (uint32_t)(a1 >> 32) + (uint32_t)(rig >> 32)),
                                               &idx[4 * q], himask);
                 }
             }
+            // publish this 16x16's trackers (ME-buffer indices: z16 = 4Q + zz)
+            const int z16 = 4 * Q + zz;
+#pragma unroll
+            for (int k = 0; k < 4; k++) flush(21 + 4 * z16 + k, k8[k]);
+            flush(5 + z16, k16);
+            flush(95 + 2 * z16, k16x8[0]); flush(95 + 2 * z16 + 1, k16x8[1]);
+            flush(137 + 2 * z16, k8x16[0]); flush(137 + 2 * z16 + 1, k8x16[1]);
+            if (C == 1) { flush(169 + 4 * Q + 2 * R, k32x8[0]); flush(169 + 4 * Q + 2 * R + 1, k32x8[1]); }
+            if (R == 1) { flush(185 + 4 * Q + 2 * C, k8x32[0]); flush(185 + 4 * Q + 2 * C + 1, k8x32[1]); }
         }
         // 32x16 (top / bottom) and 16x32 (left / right) of the quadrant: packed sums of two 16x16 (<= 65280 still fits 16 bits)
         uint32_t r32x16lo[2][4], r32x16hi[2][4], r16x32lo[2][4], r16x32hi[2][4];
+        uint32_t k32x16[2] = {0xffffffffu, 0xffffffffu}, k16x32[2] = {0xffffffffu, 0xffffffffu}, k32 = 0xffffffffu;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
 #pragma unroll
@@ -256,8 +275,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 r16x32lo[k][q] = s16lo[k][q] + s16lo[k + 2][q];
                 r16x32hi[k][q] = s16hi[k][q] + s16hi[k + 2][q];
                 if (!(Q == 2 && k == 1))  // 32x16[5] follows the stale-variable recurrence instead (wave-uniform branch)
-                    b32x16[k] = track4(b32x16[k], pack64(r32x16lo[k][q], r32x16hi[k][q]), &idx[4 * q], himask);
-                b16x32[k] = track4(b16x32[k], pack64(r16x32lo[k][q], r16x32hi[k][q]), &idx[4 * q], himask);
+                    k32x16[k] = track4(k32x16[k], pack64(r32x16lo[k][q], r32x16hi[k][q]), &idx[4 * q], himask);
+                k16x32[k] = track4(k16x32[k], pack64(r16x32lo[k][q], r16x32hi[k][q]), &idx[4 * q], himask);
             }
         }
 
@@ -278,8 +297,13 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         for (int i = 0; i < 16; i += 2) {
             uint32_t k0 = (s32acc[i] << 14) | idx[i];
             uint32_t k1 = (s32acc[i + 1] << 14) | idx[i + 1];
-            best32 = min3u(best32, k0, k1);
+            k32 = min3u(k32, k0, k1);
         }
+
+        flush(1 + Q, k32);
+        flush(87 + 2 * Q, k32x16[0]);
+        if (Q != 2) flush(87 + 2 * Q + 1, k32x16[1]);  // PU 92 (32x16[5]) follows the recurrence
+        flush(129 + 2 * Q, k16x32[0]); flush(129 + 2 * Q + 1, k16x32[1]);
 
         // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
         __syncthreads();  // previous iteration's readers are done
@@ -300,6 +324,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
             const uint32_t q0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, q1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
             const uint32_t q2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, q3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+            uint32_t kc[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t top = q0[j] + q1[j], bot = q2[j] + q3[j], lef = q0[j] + q2[j], rig = q1[j] + q3[j], all = top + bot;
@@ -307,12 +332,13 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 const bool better = (all < best64_raw) && cidx[j] != 0xffffffffu;
                 best64_raw = better ? all : best64_raw;
                 best64_idx = better ? cidx[j] : best64_idx;
-                bcross[0] = min(bcross[0], (top << 14) | cidx[j]);   // 64x32[0]   (<= 261120 < 2^18)
-                bcross[1] = min(bcross[1], (bot << 14) | cidx[j]);   // 64x32[1]
-                bcross[2] = min(bcross[2], (lef << 14) | cidx[j]);   // 32x64[0]
-                bcross[3] = min(bcross[3], (rig << 14) | cidx[j]);   // 32x64[1]
+                kc[0] = min(kc[0], (top << 14) | cidx[j]);   // 64x32[0]   (<= 261120 < 2^18)
+                kc[1] = min(kc[1], (bot << 14) | cidx[j]);   // 64x32[1]
+                kc[2] = min(kc[2], (lef << 14) | cidx[j]);   // 32x64[0]
+                kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
                 qa[lane * 16 + 4 * Q + j] = bot;                     // 64x32[1] per position, for the 32x16[5] recurrence
             }
+            flush(85, kc[0]); flush(86, kc[1]); flush(127, kc[2]); flush(128, kc[3]);
         }
         // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
         __syncthreads();
@@ -332,7 +358,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         __syncthreads();
         {
             // positions 4Q..4Q+3 = dwords (2Q, 2Q+1) of each PU's 8-dword run: [w][R] at xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q
-            uint32_t pr[4][2][4];
+            uint32_t pr[4][2][4], kd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
@@ -342,11 +368,12 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                bcross[4] = min(bcross[4], ((pr[0][0][j] + pr[1][0][j]) << 14) | cidx[j]);  // 64x16[0] = 32x16[0] + 32x16[2]
-                bcross[5] = min(bcross[5], ((pr[0][1][j] + pr[1][1][j]) << 14) | cidx[j]);  // 64x16[1] = 32x16[1] + 32x16[3]
-                bcross[6] = min(bcross[6], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
-                bcross[7] = min(bcross[7], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
+                kd[0] = min(kd[0], ((pr[0][0][j] + pr[1][0][j]) << 14) | cidx[j]);  // 64x16[0] = 32x16[0] + 32x16[2]
+                kd[1] = min(kd[1], ((pr[0][1][j] + pr[1][1][j]) << 14) | cidx[j]);  // 64x16[1] = 32x16[1] + 32x16[3]
+                kd[2] = min(kd[2], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
+                kd[3] = min(kd[3], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
             }
+            flush(201, kd[0]); flush(202, kd[1]); flush(203, kd[2]); flush(204, kd[3]);
         }
         // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
         __syncthreads();
@@ -359,7 +386,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         }
         __syncthreads();
         {
-            uint32_t pc[4][2][4];
+            uint32_t pc[4][2][4], ke[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
@@ -369,11 +396,12 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                bcross[8] = min(bcross[8], ((pc[0][0][j] + pc[2][0][j]) << 14) | cidx[j]);    // 16x64[0] = 16x32[0] + 16x32[4]
-                bcross[9] = min(bcross[9], ((pc[0][1][j] + pc[2][1][j]) << 14) | cidx[j]);    // 16x64[1] = 16x32[1] + 16x32[5]
-                bcross[10] = min(bcross[10], ((pc[1][0][j] + pc[3][0][j]) << 14) | cidx[j]);  // 16x64[2] = 16x32[2] + 16x32[6]
-                bcross[11] = min(bcross[11], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
+                ke[0] = min(ke[0], ((pc[0][0][j] + pc[2][0][j]) << 14) | cidx[j]);    // 16x64[0] = 16x32[0] + 16x32[4]
+                ke[1] = min(ke[1], ((pc[0][1][j] + pc[2][1][j]) << 14) | cidx[j]);    // 16x64[1] = 16x32[1] + 16x32[5]
+                ke[2] = min(ke[2], ((pc[1][0][j] + pc[3][0][j]) << 14) | cidx[j]);  // 16x64[2] = 16x32[2] + 16x32[6]
+                ke[3] = min(ke[3], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
             }
+            flush(205, ke[0]); flush(206, ke[1]); flush(207, ke[2]); flush(208, ke[3]);
         }
         if (Q == 0) {
             // 32x16[5] (:343-347): in raster order, "if (sad of 64x32[1] < best) best = sad of 32x16[5]".  The items of an
@@ -409,72 +437,33 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         }
     }
 
-    // ---- reduce across the wave and publish ----
+    // ---- publish: every PU's key is in LDS (64x64 as a 64-bit (raw, idx) pair, PU 92 from the recurrence state) ----
     uint32_t* osad = out_sad + (size_t)209 * sbi;
     uint32_t* omv = out_mv + (size_t)209 * sbi;
-
-    uint32_t red[21];
-#pragma unroll
-    for (int i = 0; i < 16; i++) red[i] = wave_min_u32(best8[i]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) red[16 + i] = wave_min_u32(best16[i]);
-    red[20] = wave_min_u32(best32);
     const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
-    uint32_t rr[28];  // in-quadrant rectangles: 16x8[8] 8x16[8] 32x8[4] 8x32[4] 32x16[2] 16x32[2]
-#pragma unroll
-    for (int i = 0; i < 8; i++) { rr[i] = wave_min_u32(b16x8[i]); rr[8 + i] = wave_min_u32(b8x16[i]); }
-#pragma unroll
-    for (int i = 0; i < 4; i++) { rr[16 + i] = wave_min_u32(b32x8[i]); rr[20 + i] = wave_min_u32(b8x32[i]); }
-    rr[24] = wave_min_u32(b32x16[0]); rr[25] = wave_min_u32(b32x16[1]); rr[26] = wave_min_u32(b16x32[0]); rr[27] = wave_min_u32(b16x32[1]);
-#pragma unroll
-    for (int i = 0; i < 12; i++) bcross[i] = wave_min_u32(bcross[i]);
-
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            const uint32_t key = red[i];
-            uint32_t raw, id;
-            int pu;
-            if (i < 16) { raw = key >> 16; id = key & 0x3fffu; pu = 21 + 16 * Q + i; }
-            else if (i < 20) { raw = key >> 16; id = key & 0x3fffu; pu = 5 + 4 * Q + (i - 16); }
-            else { raw = key >> 14; id = key & 0x3fffu; pu = 1 + Q; }
+    if (lane == 0) atomicMin(best64_lds, k64);
+    __syncthreads();
+    if (tid < 209) {
+        const int pu = tid;
+        uint32_t raw, id;
+        if (pu == 0) {
+            const unsigned long long k = *best64_lds;
+            raw = (uint32_t)(k >> 32);
+            id = (uint32_t)k;
+        } else {
+            // 32x32 and the cross-quadrant rectangles carry raw << 14, everything else raw << 16 (idx = y * 128 + x, 14 bits)
+            const bool wide = (pu >= 1 && pu <= 4) || pu == 85 || pu == 86 || pu == 127 || pu == 128 || pu >= 201;
+            const uint32_t key = pu_key[pu];
+            raw = wide ? key >> 14 : key >> 16;
+            id = key & 0x3fffu;
+        }
+        if (pu != 92) {
             osad[pu] = 2u * raw;
             omv[pu] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
         }
-#pragma unroll
-        for (int i = 0; i < 28; i++) {
-            // ME-buffer index of the rectangle (Codec/EbMotionEstimationContext.h:132-261; index algebra in DESIGN 3.1)
-            int pu;
-            if (i < 8) pu = 95 + 8 * Q + i;                    // 16x8[2 * z16 + part], z16 = 4Q + zz
-            else if (i < 16) pu = 137 + 8 * Q + (i - 8);       // 8x16[2 * z16 + side]
-            else if (i < 20) pu = 169 + 4 * Q + (i - 16);      // 32x8[4Q + 2R + part]
-            else if (i < 24) pu = 185 + 4 * Q + (i - 20);      // 8x32[4Q + 2C + side]
-            else if (i < 26) pu = 87 + 2 * Q + (i - 24);       // 32x16[2Q + R]
-            else pu = 129 + 2 * Q + (i - 26);                  // 16x32[2Q + C]
-            if (pu == 92) continue;                            // 32x16[5]: written by wave 0 below
-            const uint32_t key = rr[i];
-            osad[pu] = 2u * (key >> 16);
-            omv[pu] = mv_word(xo + (int)(key & 127u), yo + (int)((key >> 7) & 127u));
-        }
-        atomicMin(best64_lds, k64);
-#pragma unroll
-        for (int i = 0; i < 12; i++) atomicMin(&cross_lds[i], bcross[i]);
-        if (Q == 0) {
-            osad[92] = 2u * q5_raw;
-            omv[92] = mv_word(xo + (int)(q5_idx & 127u), yo + (int)(q5_idx >> 7));
-        }
     }
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long k = *best64_lds;
-        const uint32_t raw = (uint32_t)(k >> 32), id = (uint32_t)k;
-        osad[0] = 2u * raw;
-        omv[0] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
-    }
-    if (tid < 12) {
-        const int pu = tid < 2 ? 85 + tid : (tid < 4 ? 127 + (tid - 2) : (tid < 8 ? 201 + (tid - 4) : 205 + (tid - 8)));
-        const uint32_t key = cross_lds[tid];
-        osad[pu] = 2u * (key >> 14);
-        omv[pu] = mv_word(xo + (int)(key & 127u), yo + (int)((key >> 7) & 127u));
+    if (tid == 0) {  // wave 0 holds the (wave-uniform) state of the 32x16[5] recurrence
+        osad[92] = 2u * q5_raw;
+        omv[92] = mv_word(xo + (int)(q5_idx & 127u), yo + (int)(q5_idx >> 7));
     }
 }
