@@ -135,16 +135,21 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     uint32_t q5_raw = 0xffffffffu, q5_idx = 0;  // PU 32x16[5]: wave-uniform state of the recurrence (wave 0 only)
 
     const uint32_t himask = 0xffff0000u;
-    auto flush = [&](int pu, uint32_t key) {  // wave-wide minimum of a tracker -> the PU's LDS key
-        // four DPP steps leave every row of 16 lanes with its minimum, four v_readlane + scalar min combine the rows: 8 VALU
-        // instructions and no LDS round trips (61 of these per iteration: ds_bpermute shuffles cost +40 % kernel time)
-        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x141, 0xf, 0xf, false));  // row_half_mirror
-        key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x140, 0xf, 0xf, false));  // row_mirror
-        const uint32_t m = min(min((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16)),
-                               min((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48)));
-        if (lane == 0) atomicMin(&pu_key[pu], m);
+    // LDS minimum without return value.  atomicMin() would do, but its lowering wraps every call in a "first active lane"
+    // sequence (v_mbcnt + branch) although the call already sits in a lane-0 block: 60 extra branches per iteration.
+    auto lds_min = [&](uint32_t* p, uint32_t v) {
+        const uint32_t off = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)p);
+        asm volatile("ds_min_u32 %0, %1" ::"v"(off), "v"(v) : "memory");
+    };
+    // wave-wide minimum as a scalar: four fused DPP min steps leave every row of 16 lanes with its minimum, four v_readlane +
+    // scalar min combine the rows: 8 VALU instructions, no LDS round trips (61 reductions per iteration)
+    auto wmin = [&](uint32_t key) -> uint32_t {
+        asm("v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(key));
+        asm("v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(key));
+        asm("v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(key));
+        asm("v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(key));
+        return min(min((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16)),
+                   min((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48)));
     };
     const int n_items = n_xg * sh;
     const int n_iter = (n_items + 63) >> 6;
@@ -253,15 +258,22 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                                               &idx[4 * q], himask);
                 }
             }
-            // publish this 16x16's trackers (ME-buffer indices: z16 = 4Q + zz)
+            // publish this 16x16's trackers (ME-buffer indices: z16 = 4Q + zz): reduce first, then one lane-0 block of ds_min
             const int z16 = 4 * Q + zz;
+            const uint32_t m8[4] = {wmin(k8[0]), wmin(k8[1]), wmin(k8[2]), wmin(k8[3])};
+            const uint32_t m16 = wmin(k16), mt = wmin(k16x8[0]), mb = wmin(k16x8[1]), ml = wmin(k8x16[0]), mr = wmin(k8x16[1]);
+            uint32_t mw0 = 0, mw1 = 0, mh0 = 0, mh1 = 0;
+            if (C == 1) { mw0 = wmin(k32x8[0]); mw1 = wmin(k32x8[1]); }
+            if (R == 1) { mh0 = wmin(k8x32[0]); mh1 = wmin(k8x32[1]); }
+            if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) flush(21 + 4 * z16 + k, k8[k]);
-            flush(5 + z16, k16);
-            flush(95 + 2 * z16, k16x8[0]); flush(95 + 2 * z16 + 1, k16x8[1]);
-            flush(137 + 2 * z16, k8x16[0]); flush(137 + 2 * z16 + 1, k8x16[1]);
-            if (C == 1) { flush(169 + 4 * Q + 2 * R, k32x8[0]); flush(169 + 4 * Q + 2 * R + 1, k32x8[1]); }
-            if (R == 1) { flush(185 + 4 * Q + 2 * C, k8x32[0]); flush(185 + 4 * Q + 2 * C + 1, k8x32[1]); }
+                for (int k = 0; k < 4; k++) lds_min(&pu_key[21 + 4 * z16 + k], m8[k]);
+                lds_min(&pu_key[5 + z16], m16);
+                lds_min(&pu_key[95 + 2 * z16], mt); lds_min(&pu_key[95 + 2 * z16 + 1], mb);
+                lds_min(&pu_key[137 + 2 * z16], ml); lds_min(&pu_key[137 + 2 * z16 + 1], mr);
+                if (C == 1) { lds_min(&pu_key[169 + 4 * Q + 2 * R], mw0); lds_min(&pu_key[169 + 4 * Q + 2 * R + 1], mw1); }
+                if (R == 1) { lds_min(&pu_key[185 + 4 * Q + 2 * C], mh0); lds_min(&pu_key[185 + 4 * Q + 2 * C + 1], mh1); }
+            }
         }
         // 32x16 (top / bottom) and 16x32 (left / right) of the quadrant: packed sums of two 16x16 (<= 65280 still fits 16 bits)
         uint32_t r32x16lo[2][4], r32x16hi[2][4], r16x32lo[2][4], r16x32hi[2][4];
@@ -300,10 +312,15 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             k32 = min3u(k32, k0, k1);
         }
 
-        flush(1 + Q, k32);
-        flush(87 + 2 * Q, k32x16[0]);
-        if (Q != 2) flush(87 + 2 * Q + 1, k32x16[1]);  // PU 92 (32x16[5]) follows the recurrence
-        flush(129 + 2 * Q, k16x32[0]); flush(129 + 2 * Q + 1, k16x32[1]);
+        {
+            const uint32_t m32 = wmin(k32), ma = wmin(k32x16[0]), mb = wmin(k32x16[1]), mc = wmin(k16x32[0]), md = wmin(k16x32[1]);
+            if (lane == 0) {
+                lds_min(&pu_key[1 + Q], m32);
+                lds_min(&pu_key[87 + 2 * Q], ma);
+                if (Q != 2) lds_min(&pu_key[87 + 2 * Q + 1], mb);  // PU 92 (32x16[5]) follows the recurrence
+                lds_min(&pu_key[129 + 2 * Q], mc); lds_min(&pu_key[129 + 2 * Q + 1], md);
+            }
+        }
 
         // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
         __syncthreads();  // previous iteration's readers are done
@@ -338,7 +355,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
                 qa[lane * 16 + 4 * Q + j] = bot;                     // 64x32[1] per position, for the 32x16[5] recurrence
             }
-            flush(85, kc[0]); flush(86, kc[1]); flush(127, kc[2]); flush(128, kc[3]);
+            const uint32_t mk[4] = {wmin(kc[0]), wmin(kc[1]), wmin(kc[2]), wmin(kc[3])};
+            if (lane == 0) { lds_min(&pu_key[85], mk[0]); lds_min(&pu_key[86], mk[1]); lds_min(&pu_key[127], mk[2]); lds_min(&pu_key[128], mk[3]); }
         }
         // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
         __syncthreads();
@@ -373,7 +391,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 kd[2] = min(kd[2], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
                 kd[3] = min(kd[3], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
             }
-            flush(201, kd[0]); flush(202, kd[1]); flush(203, kd[2]); flush(204, kd[3]);
+            const uint32_t mk[4] = {wmin(kd[0]), wmin(kd[1]), wmin(kd[2]), wmin(kd[3])};
+            if (lane == 0) { lds_min(&pu_key[201], mk[0]); lds_min(&pu_key[202], mk[1]); lds_min(&pu_key[203], mk[2]); lds_min(&pu_key[204], mk[3]); }
         }
         // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
         __syncthreads();
@@ -401,7 +420,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 ke[2] = min(ke[2], ((pc[1][0][j] + pc[3][0][j]) << 14) | cidx[j]);  // 16x64[2] = 16x32[2] + 16x32[6]
                 ke[3] = min(ke[3], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
             }
-            flush(205, ke[0]); flush(206, ke[1]); flush(207, ke[2]); flush(208, ke[3]);
+            const uint32_t mk[4] = {wmin(ke[0]), wmin(ke[1]), wmin(ke[2]), wmin(ke[3])};
+            if (lane == 0) { lds_min(&pu_key[205], mk[0]); lds_min(&pu_key[206], mk[1]); lds_min(&pu_key[207], mk[2]); lds_min(&pu_key[208], mk[3]); }
         }
         if (Q == 0) {
             // 32x16[5] (:343-347): in raster order, "if (sad of 64x32[1] < best) best = sad of 32x16[5]".  The items of an
@@ -442,6 +462,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     uint32_t* omv = out_mv + (size_t)209 * sbi;
     const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
     if (lane == 0) atomicMin(best64_lds, k64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ds_min_u32 above are invisible to the compiler's counter tracking
     __syncthreads();
     if (tid < 209) {
         const int pu = tid;
