@@ -63,7 +63,53 @@ def interp_fixture():
     np.savez_compressed(os.path.join(HERE, "interp_planes.npz"), img=img, off=off, sw=24, sh=16, b=b, h=hh, j=j)
 
 
+def fullpel209_fixture():
+    """209-PU full-pel search through the reference's ExtSadCalculation* functions (oracle/ref_fullpel209_driver.c)."""
+    refme = ReferenceME()
+    rng = np.random.default_rng(20261005)
+    w, h = 192, 136
+    cur_img, ref_img = synth.synth_luma(w, h, 2), synth.synth_luma(w, h, 0)
+    cur, rf = synth.PaPicture(cur_img), synth.PaPicture(ref_img)
+    cases = {}
+    for name, search in (("s64", (64, 64)), ("s40x17", (40, 17))):
+        centers = rng.integers(-30, 31, size=(9, 2))
+        desc = svtav1_hip.make_fullpel_desc(cur, rf, centers, *search)
+        sad, mv = refme.fullpel_search209_batch(cur.full, rf.full, desc)
+        cases[name + "_desc"], cases[name + "_sad"], cases[name + "_mv"] = desc, sad, mv
+    np.savez_compressed(os.path.join(HERE, "fullpel_209pu.npz"), cur=cur_img, ref=ref_img, **cases)
+
+
+def transform_fixture():
+    """Forward transform, quantiser and inverse transform + reconstruction through the reference's C functions
+    (oracle/_ref/libsvtref_tq.so) for the five square sizes, DCT_DCT and one more type each."""
+    import ctypes as C
+    tq = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_tq.so"))
+    rng = np.random.default_rng(20261006)
+    out = {}
+    for n in (4, 8, 16, 32, 64):
+        for tx_type in ((0, 3) if n <= 16 else ((0, 9) if n == 32 else (0,))):   # DCT_DCT, ADST_ADST / IDTX
+            yy, xx = np.mgrid[0:n, 0:n]
+            res = np.clip(40 * np.sin(xx / 3.0) * np.cos(yy / 4.0) + rng.integers(-20, 21, (n, n)), -255, 255).astype(np.int16)
+            coeff = np.zeros(n * n, np.int32)
+            f = getattr(tq, f"Av1TransformTwoD_{n}x{n}_c"); f.restype = None
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint8]
+            f(res.ctypes.data, coeff.ctypes.data, n, tx_type, 8)
+            m = min(n, 32)
+            packed = np.ascontiguousarray(coeff.reshape(n, n)[:m, :m]).reshape(-1)      # what Av1EstimateTransform keeps
+            pred = rng.integers(0, 256, (n, n)).astype(np.uint16)
+            rec = pred.copy()
+            dq = (packed // 8 * 8).astype(np.int32)                                      # a coarse "dequantised" block
+            g = getattr(tq, f"av1_inv_txfm2d_add_{n}x{n}_c"); g.restype = None
+            g.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int32]
+            g(dq.ctypes.data, rec.ctypes.data, n, tx_type, 8)
+            k = f"n{n}_t{tx_type}_"
+            out[k + "res"], out[k + "coeff"], out[k + "dq"], out[k + "pred"], out[k + "rec"] = res, coeff, dq, pred, rec
+    np.savez_compressed(os.path.join(HERE, "transforms.npz"), **out)
+
+
 if __name__ == "__main__":
+    fullpel209_fixture()
+    transform_fixture()
     fullpel_fixture()
     me_chain_fixture()
     interp_fixture()
