@@ -302,15 +302,20 @@ __device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TW
         valid[7] = (d == DIR_B || d == DIR_BL || d == DIR_L);
         valid[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
     }
-    const int qdx[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, qdy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    // every direction enables exactly three of the eight positions; each lane group walks ITS three in ascending order (the
+    // reference's evaluation order), so all groups of a wave run three passes whatever their directions are
+    uint32_t vmask = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        // a candidate is evaluated when any lane group of the wave needs it (<= 3 per group); groups that do not need it
-        // compute it too but ignore the result, which keeps the wave convergent for the group reductions
-        if (__ballot(valid[k]) == 0) continue;
+    for (int k = 0; k < 8; k++) vmask |= valid[k] ? (1u << k) : 0u;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+        const int k = __builtin_ctz(vmask);  // lowest remaining position of this group
+        vmask &= vmask - 1;
         const int q1 = kQuarter[method][k][0], q2 = kQuarter[method][k][1];
         const int p1 = q1 & 3, dx1 = ((q1 >> 2) & 3) - 1, dy1 = ((q1 >> 4) & 3) - 1;
         const int p2 = q2 & 3, dx2 = ((q2 >> 2) & 3) - 1, dy2 = ((q2 >> 4) & 3) - 1;
+        // L, R, T, B, TL, TR, BR, BL: dx = {-1, 1, 0, 0, -1, 1, 1, -1}, dy = {0, 0, -1, 1, -1, -1, 1, 1}, two bits each (+1)
+        const int qdx = (int)((0x2858u >> (2 * k)) & 3u) - 1, qdy = (int)((0xA085u >> (2 * k)) & 3u) - 1;
         uint32_t ssd = 0, sad = 0;
 #pragma unroll 2
         for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
@@ -324,9 +329,9 @@ __device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TW
         }
         ssd = gsum<LPP>(ssd);
         sad = gsum<LPP>(sad);
-        if (valid[k] && ssd < best_ssd) {
+        if (ssd < best_ssd) {
             best_sad = sad;
-            best_mv = ((uint32_t)(uint16_t)(y_mv + qdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + qdx[k]);
+            best_mv = ((uint32_t)(uint16_t)(y_mv + qdy) << 16) | (uint32_t)(uint16_t)(x_mv + qdx);
             best_ssd = ssd;
         }
     }
