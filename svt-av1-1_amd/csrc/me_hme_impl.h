@@ -45,8 +45,19 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // SAD of a W x H block (strides already doubled by the caller), computed by one wave.  W need not be a
 // multiple of 4: the tail dword is masked on both operands.
 __device__ uint32_t wave_block_sad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride,
-                                   uint32_t H, uint32_t W, int lane)
+                                   uint32_t H, uint32_t W, int lane, const uint32_t* src_lds = nullptr)
 {
+    if (src_lds && W == 64 && H == 32) {
+        // the 64 x 32-row source block is already in LDS ([32][16] dwords): only the reference rows come from memory
+        const uint32_t c = (uint32_t)lane & 15u, r0 = (uint32_t)lane >> 4;
+        const uint8_t* rp = ref + (size_t)r0 * ref_stride + 4u * c;
+        uint32_t tv[8], acc4 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) tv[k] = ldu32_nb(rp + (size_t)(4 * k) * ref_stride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc4 = __builtin_amdgcn_sad_u8(src_lds[(r0 + 4 * k) * 16 + c], tv[k], acc4);
+        return wave_sum_u32(acc4);
+    }
     if (W == 64 && (H & 3u) == 0) {
         // full-width block: lane = (row mod 4, dword column), four rows per pass, all loads of a lane in flight together;
         // src is dword aligned (SB origin multiple of 64), ref is re-aligned from aligned pairs
@@ -195,18 +206,21 @@ __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t 
 //   * when a level has fewer than 64 items (HME L1 / L2), RP lanes share an item and split its block rows;
 //   * best position: 64-bit key (sad << 32 | raster index), lane-local strict min, then a wave min.
 // `lds` is this wave's private slice of `lds_bytes` bytes; the search area is processed in bands of rows that fit.
+// `shared_src` (may be null): the H x W source block already staged in LDS by the workgroup ([H][W / 4] dwords, shared by the
+// four region waves); then the whole slice holds the window.
 template <int W>
 __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride_raw,
                                   int H, int sw, int sh, int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad,
-                                  int* bx, int* by)
+                                  int* bx, int* by, const uint32_t* shared_src = nullptr)
 {
     constexpr int WD = W / 4;                 // source dwords per block row
     constexpr int FLUSH = (W == 16) ? 16 : (W == 32 ? 8 : 4);  // rows a u16 accumulator can take: rows*W*255 < 65536
-    uint32_t* srcbuf = reinterpret_cast<uint32_t*>(lds);       // [H][WD]
+    const int own_src = shared_src ? 0 : H * WD;
+    const uint32_t* srcbuf = shared_src ? shared_src : reinterpret_cast<const uint32_t*>(lds);  // [H][WD]
     const int noct = (sw + 7) >> 3;
     const int pitch = 2 * noct + WD + 1;      // window dwords per row (+1: odd pitch spreads rows over banks)
-    uint32_t* win = srcbuf + H * WD;
-    const int avail_rows = (lds_bytes / 4 - H * WD) / pitch;
+    uint32_t* win = reinterpret_cast<uint32_t*>(lds) + own_src;
+    const int avail_rows = (lds_bytes / 4 - own_src) / pitch;
     int band = avail_rows - (2 * H - 2);      // search rows per band
     if (band > sh) band = sh;
     if (band < 1) {  // window row wider than the slice (cannot happen for the reference's parameter ranges)
@@ -216,7 +230,7 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     }
 
     // source block -> LDS (rows are src_stride apart, already the doubled stride); 4 dwords per lane in flight
-    for (int i0 = 0; i0 < H * WD; i0 += 256) {
+    for (int i0 = 0; !shared_src && i0 < H * WD; i0 += 256) {
         uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -225,7 +239,7 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
             v[k] = ldu32_nb(src + (uint32_t)r * src_stride + 4u * (uint32_t)c);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) srcbuf[min(i0 + k * 64 + lane, H * WD - 1)] = v[k];
+        for (int k = 0; k < 4; k++) reinterpret_cast<uint32_t*>(lds)[min(i0 + k * 64 + lane, H * WD - 1)] = v[k];
     }
 
     // items and row-parts
@@ -313,21 +327,24 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
 // scalar multiple of the pitch.  A 16x8 SAD is < 2^16 and the area has < 2^16 positions, so the best position is a 32-bit
 // (sad << 16 | raster index) minimum, which is the reference's strict-'<' raster rule.
 __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride_raw, int sw, int sh,
-                                 int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad, int* bx, int* by)
+                                 int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad, int* bx, int* by,
+                                 const uint32_t* shared_src = nullptr)
 {
     constexpr int H = 8, WD = 4;
-    uint32_t* srcbuf = reinterpret_cast<uint32_t*>(lds);  // [8][4]
+    const int own_src = shared_src ? 0 : H * WD;
+    const uint32_t* srcbuf = shared_src ? shared_src : reinterpret_cast<const uint32_t*>(lds);  // [8][4], 16-byte aligned
     const int nit = (sw + 15) >> 4;                       // items per search row
     const int pitch = 4 * nit + 4;                        // window dwords per row (multiple of 4: items stay 16-byte aligned)
-    uint32_t* win = srcbuf + H * WD;
-    const int avail_rows = (lds_bytes / 4 - H * WD) / pitch;
+    uint32_t* win = reinterpret_cast<uint32_t*>(lds) + own_src;
+    const int avail_rows = (lds_bytes / 4 - own_src) / pitch;
     int band = avail_rows - (2 * H - 2);
     if (band > sh) band = sh;
     if (band < 1 || sw * sh > 65536) {
-        wave_sad_loop_lds<16>(src, src_stride, ref, ref_stride_raw, H, sw, sh, lane, lds, lds_bytes, best_sad, bx, by);
+        wave_sad_loop_lds<16>(src, src_stride, ref, ref_stride_raw, H, sw, sh, lane, lds, lds_bytes, best_sad, bx, by, shared_src);
         return;
     }
-    if (lane < H * WD) srcbuf[lane] = ldu32_nb(src + (uint32_t)(lane >> 2) * src_stride + 4u * (uint32_t)(lane & 3));
+    if (!shared_src && lane < H * WD)
+        reinterpret_cast<uint32_t*>(lds)[lane] = ldu32_nb(src + (uint32_t)(lane >> 2) * src_stride + 4u * (uint32_t)(lane & 3));
     uint32_t best = 0xffffffffu;
     const uint32_t inv_nit = (1u << 20) / (uint32_t)nit + 1u;
     for (int y0 = 0; y0 < sh; y0 += band) {
@@ -419,6 +436,11 @@ struct HmeShared {
     unsigned long long rs[3][4];  // per level SADs (doubled)
     int cx, cy;
     svthip_fullpel_desc desc;     // the final descriptor, for a consumer in the same workgroup
+    // source blocks of a full 64x64 SB, staged once for the four region waves: full-res rows 0,2,..,62 (64 x 32), quarter-res
+    // rows 0,2,..,30 (32 x 16), sixteenth-res rows 0,2,..,14 (16 x 8)
+    __attribute__((aligned(16))) uint32_t src2[32 * 16];
+    __attribute__((aligned(16))) uint32_t src1[16 * 8];
+    __attribute__((aligned(16))) uint32_t src0[8 * 4];
 };
 
 
@@ -442,6 +464,27 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
     const uint8_t* ref_full = pool + ref.full_offset + (size_t)68 * ref.full_stride + 68;
     const uint8_t* src = cur_full + (size_t)oy * cur.full_stride + ox;
 
+    // full 64x64 SBs: stage the three source blocks once for the whole workgroup (the four region waves search with the same
+    // block at every level, and the centre checks compare the same 64 x 32-row block)
+    const bool full_sb = sb_w == 64 && sb_h == 64;
+    if (full_sb) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + 256 * k;  // 512 dwords of the full-res block, dword aligned (SB origin multiple of 64)
+            sh.src2[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(i >> 4) * (cur.full_stride * 2) + 4 * (i & 15));
+        }
+        if (tid < 128) {
+            const uint8_t* s1 = pool + cur.quarter_offset + (size_t)(32 + (oy >> 1)) * cur.quarter_stride + 32 + (ox >> 1);
+            sh.src1[tid] = ldu32_nb(s1 + (size_t)(tid >> 3) * (cur.quarter_stride * 2) + 4 * (tid & 7));
+        } else if (tid < 160) {
+            const int i = tid - 128;
+            const uint8_t* s0 = pool + cur.sixteenth_offset + (size_t)(16 + (oy >> 2)) * cur.sixteenth_stride + 16 + (ox >> 2);
+            sh.src0[i] = ldu32_nb(s0 + (size_t)(i >> 2) * (cur.sixteenth_stride * 2) + 4 * (i & 3));
+        }
+        __syncthreads();
+    }
+    const uint32_t* src2_lds = full_sb ? sh.src2 : nullptr;
+
     const bool center_path = (P.temporal_layer_index > 0) || (list_index == 0);  // :6300
     const uint32_t mv64 = (list_index == 1 && l0_best_mv64) ? l0_best_mv64[(size_t)sbi * l0_mv_stride] : 0u;
     const int dx = s16(0 - (s16((int)(mv64 & 0xffffu)) >> 2));
@@ -459,7 +502,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
             int x = cxs[c], y = cys[c];
             clamp_center(x, y, ox, oy, ref.width, ref.height);
             const uint32_t sad = wave_block_sad(src, cur.full_stride * 2, ref_full + (size_t)(oy + y) * ref.full_stride + ox + x,
-                                                ref.full_stride * 2, sb_h >> 1, sb_w, lane);
+                                                ref.full_stride * 2, sb_h >> 1, sb_w, lane, src2_lds);
             if (lane == 0) sh.cost[c] = (unsigned long long)(sad << 1) << 8;
         }
         __syncthreads();
@@ -504,7 +547,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     int bx, by;
                     if (sb_w == 64)
                         wave_sad_loop_l0(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride, sw, shh, lane, wlds, kHmeLdsPerWave, &sad0,
-                                         &bx, &by);
+                                         &bx, &by, sh.src0);
                     else
                         wave_sad_loop_generic(s, cur.sixteenth_stride * 2, r, ref.sixteenth_stride * 2, (sb_h >> 2) >> 1, sb_w >> 2,
                                               ref.sixteenth_stride, sw, shh, lane, &sad0, &bx, &by);
@@ -522,7 +565,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     int bx, by;
                     if (sb_w == 64)
                         wave_sad_loop_lds<32>(s, cur.quarter_stride * 2, r, ref.quarter_stride, 16, sw, shh, lane, wlds,
-                                              kHmeLdsPerWave, &sad1, &bx, &by);
+                                              kHmeLdsPerWave, &sad1, &bx, &by, sh.src1);
                     else
                         wave_sad_loop_generic(s, cur.quarter_stride * 2, r, ref.quarter_stride * 2, (sb_h >> 1) >> 1, sb_w >> 1,
                                               ref.quarter_stride, sw, shh, lane, &sad1, &bx, &by);
@@ -538,7 +581,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     int bx, by;
                     if (sb_w == 64)
                         wave_sad_loop_lds<64>(src, cur.full_stride * 2, r, ref.full_stride, 32, sw, shh, lane, wlds,
-                                              kHmeLdsPerWave, &sad2, &bx, &by);
+                                              kHmeLdsPerWave, &sad2, &bx, &by, sh.src2);
                     else
                         wave_sad_loop_generic(src, cur.full_stride * 2, r, ref.full_stride * 2, sb_h >> 1, sb_w, ref.full_stride, sw,
                                               shh, lane, &sad2, &bx, &by);
@@ -619,7 +662,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
         if (wave < 2) {
             const int x = wave ? xc : 0, y = wave ? yc : 0;
             const uint32_t sad = wave_block_sad(src, cur.full_stride * 2, ref_full + (size_t)(oy + y) * ref.full_stride + ox + x,
-                                                ref.full_stride * 2, sb_h >> 1, sb_w, lane);
+                                                ref.full_stride * 2, sb_h >> 1, sb_w, lane, src2_lds);
             if (lane == 0) sh.cost[6 + wave] = (unsigned long long)(sad << 1) << 8;
         }
         __syncthreads();
