@@ -145,3 +145,34 @@ def test_fullpel_209pu_matches_oracle(hip_ctx, oracle, case):
     s_h, m_h = d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
     bad = np.argwhere((s_h != s_o) | (m_h != m_o))
     assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}: hip {s_h[tuple(bad[0])]}/{m_h[tuple(bad[0])]:#x} oracle {s_o[tuple(bad[0])]}/{m_o[tuple(bad[0])]:#x}; PUs {sorted(set(bad[:, 1]))[:20]}"
+
+
+def test_me_entries_reject_bad_arguments(hip_ctx):
+    """Error behaviour of the C ABI: bad parameters come back as SVTHIP_ERR_BAD_PARAMETER with a message, nothing is launched."""
+    import torch
+    dev = torch.device("cuda:0")
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=dev)
+    out = torch.zeros(1 << 12, dtype=torch.int32, device=dev)
+    p = buf.data_ptr()
+    with pytest.raises(svtav1_hip.SvtHipError, match="search area"):
+        hip_ctx.fullpel_search_dev(p, 256, p, 256, p, 1, 128, 64, out.data_ptr(), out.data_ptr())          # area > 127
+    with pytest.raises(svtav1_hip.SvtHipError, match="search area"):
+        hip_ctx.fullpel_search209_dev(p, 256, p, 256, p, 1, 64, 0, out.data_ptr(), out.data_ptr())         # empty area
+    with pytest.raises(svtav1_hip.SvtHipError, match="multiples of 4"):
+        hip_ctx.fullpel_search_dev(p, 250, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr())          # stride not 4-aligned
+    with pytest.raises(svtav1_hip.SvtHipError, match="null"):
+        hip_ctx.fullpel_search209_dev(p, 256, p, 256, None, 1, 64, 64, out.data_ptr(), out.data_ptr())
+    # n_sb == 0 is a no-op, not an error
+    hip_ctx.fullpel_search_dev(p, 256, p, 256, p, 0, 64, 64, out.data_ptr(), out.data_ptr())
+    hip_ctx.fullpel_search209_dev(p, 256, p, 256, p, 0, 64, 64, out.data_ptr(), out.data_ptr())
+    pics = [synth.PaPicture(synth.synth_luma(128, 64, t)) for t in range(2)]
+    pool, pd = svtav1_hip.build_picture_pool(pics)
+    d_pool = torch.from_numpy(pool).to(dev)
+    sb = torch.from_numpy(svtav1_hip.sb_origins(128, 64).view(np.int16).copy()).to(dev)
+    P = svtav1_hip.default_me_params(128, 64, 3, 0)
+    P.number_hme_search_region_in_width = 3
+    with pytest.raises(svtav1_hip.SvtHipError, match="regions"):
+        hip_ctx.hme_search_center_dev(d_pool.data_ptr(), pd[1], pd[0], P, 0, sb.data_ptr(), 2, None, out.data_ptr())
+    P = svtav1_hip.default_me_params(128, 64, 3, 0)
+    with pytest.raises(svtav1_hip.SvtHipError, match="list_index"):
+        hip_ctx.hme_search_center_dev(d_pool.data_ptr(), pd[1], pd[0], P, 2, sb.data_ptr(), 2, None, out.data_ptr())
