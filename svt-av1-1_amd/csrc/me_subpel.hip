@@ -59,13 +59,12 @@ __device__ __forceinline__ uint32_t sub_u8x4(uint32_t a, uint32_t b)
 {
     return ((a | 0x80808080u) - (b & 0x7f7f7f7fu)) ^ ((a ^ ~b) & 0x80808080u);
 }
-// sum over 4 bytes of wrap_sq: e = |int8(s - c)| with -128 -> 128, e * e
+// sum over 4 bytes of wrap_sq: e = |int8(s - c)| with -128 -> 128, e * e.  e * e is the square of the SIGNED byte
+// difference ((-128)^2 = 128^2), so it is one signed dot product of the bytewise difference with itself.
 __device__ __forceinline__ uint32_t wssd4(uint32_t s, uint32_t c, uint32_t acc)
 {
     const uint32_t d = sub_u8x4(s, c);
-    const uint32_t m = (d >> 7) & 0x01010101u;        // 1 in every byte whose difference is negative
-    const uint32_t e = (d ^ ((m << 8) - m)) + m;      // bytewise |d|: (d ^ 0xff) + 1 <= 128 never carries
-    return __builtin_amdgcn_udot4(e, e, acc, false);
+    return (uint32_t)__builtin_amdgcn_sdot4((int)d, (int)d, (int)acc, false);
 }
 // bytewise (a + b + 1) >> 1
 __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }
