@@ -230,7 +230,7 @@ __device__ void half_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>&
 #pragma unroll
     for (int k = 0; k < 8; k++) sad[k] = 0;
     constexpr int TW = Tiles<TWd>::TW, PW4 = PW / 4;
-#pragma unroll 1  // a wider unroll makes the compiler hoist every LDS load of the 17 accumulations (256 VGPRs)
+#pragma unroll 2
     for (int i = l; i < PW4 * PW; i += LPP) {  // 4 pixels per step
         const int y = i / PW4, x = 4 * (i - y * PW4);
         const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
