@@ -127,17 +127,42 @@ class Oracle:
           mv.ctypes.data, ssd.ctypes.data, dr.ctypes.data)
         return sad, mv, ssd, dr
 
+    def pu_geometry209(self):
+        """[209,5] = w, h, px, py, ME-buffer index by raster PU index."""
+        g = np.zeros((209, 5), np.uint8)
+        self.lib.orc_pu_geometry209.restype = None
+        self.lib.orc_pu_geometry209.argtypes = [C.c_void_p]
+        self.lib.orc_pu_geometry209(g.ctypes.data)
+        return g
+
+    def subpel_refine209_batch(self, src_plane, ref_plane, desc, sad, mv, disable_8x8=False, src_stride=None, ref_stride=None):
+        """In: full-pel (sad, mv) [n,209] (ME-buffer order); out: refined copies."""
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n = desc.shape[0]
+        sad = np.ascontiguousarray(sad, dtype=np.uint32).copy()
+        mv = np.ascontiguousarray(mv, dtype=np.uint32).copy()
+        assert sad.shape == (n, 209) and mv.shape == (n, 209)
+        f = self.lib.orc_subpel_refine209_batch
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        ss = src_stride if src_stride is not None else src_plane.shape[1]
+        rs = ref_stride if ref_stride is not None else ref_plane.shape[1]
+        f(src_plane.ctypes.data, ss, ref_plane.ctypes.data, rs, desc.ctypes.data, n, int(disable_8x8), sad.ctypes.data, mv.ctypes.data)
+        return sad, mv
+
     def bipred_pack_batch(self, src_plane, src_stride, ref0_plane, ref0_stride, desc0, sad0, mv0, ref1_plane=None,
-                          ref1_stride=0, desc1=None, sad1=None, mv1=None, bipred_8x8=True):
-        """-> structured array [n,85] of svtav1_hip.ME_CU_RESULT_DTYPE (raster PU order)."""
+                          ref1_stride=0, desc1=None, sad1=None, mv1=None, bipred_8x8=True, n_pu=85):
+        """-> structured array [n,n_pu] of svtav1_hip.ME_CU_RESULT_DTYPE (raster PU order); n_pu = 85 or 209."""
         import svtav1_hip
         n = desc0.shape[0]
         n_lists = 2 if desc1 is not None else 1
-        out = np.zeros((n, 85), dtype=svtav1_hip.ME_CU_RESULT_DTYPE)
-        f = self.lib.orc_bipred_pack_batch
-        f.restype = None
-        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        out = np.zeros((n, n_pu), dtype=svtav1_hip.ME_CU_RESULT_DTYPE)
+        assert np.asarray(sad0).shape == (n, n_pu)
+        g = self.lib.orc_bipred_pack_batch_npu
+        g.restype = None
+        g.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        f = lambda *a: g(*a[:-1], n_pu, a[-1])
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         d0 = c(desc0, np.int32); s0 = c(sad0, np.uint32); m0 = c(mv0, np.uint32)
         if n_lists == 2:
@@ -245,9 +270,10 @@ class ReferenceME:
         assert rc == 0
         return b, h, j
 
-    def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0):
+    def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0, all_pu=False):
         """cur/ref0/ref1: svtav1_hip.synth.PaPicture; params: svtav1_hip.MeParams.
-        -> dict(sad [n,2,85], mv [n,2,85], origin [n,2,2], res [n,85,9])"""
+        all_pu: the 209-PU mode (NPU = 209, else 85)
+        -> dict(sad [n,2,NPU], mv [n,2,NPU], origin [n,2,2], res [n,NPU,11])"""
         w, h = cur.width, cur.height
         planes = (C.c_void_p * 9)()
         keep = []
@@ -268,12 +294,13 @@ class ReferenceME:
                        P.hme_level2_search_area_in_height_array[0], P.hme_level2_search_area_in_height_array[1],
                        P.enable_hme_flag, P.enable_hme_level0_flag, P.enable_hme_level1_flag, P.enable_hme_level2_flag,
                        int(two_lists), P.temporal_layer_index, hierarchical_levels, P.is_used_as_reference_flag, 0,
-                       10, 10 if P.ref_poc_equal else 20, asm_type], dtype=np.int32)
+                       10, 10 if P.ref_poc_equal else 20, asm_type, int(all_pu)], dtype=np.int32)
         n = ((w + 63) // 64) * ((h + 63) // 64)
-        sad = np.zeros((n, 2, 85), np.uint32)
-        mv = np.zeros((n, 2, 85), np.uint32)
+        npu = 209 if all_pu else 85
+        sad = np.zeros((n, 2, npu), np.uint32)
+        mv = np.zeros((n, 2, npu), np.uint32)
         origin = np.zeros((n, 2, 4), np.int32)
-        res = np.zeros((n, 85, 9), np.int32)
+        res = np.zeros((n, npu, 11), np.int32)
         rc = self.lib.ref_me_lcu_run(planes, w, h, ip.ctypes.data, sad.ctypes.data, mv.ctypes.data, origin.ctypes.data,
                                      res.ctypes.data)
         if rc != 0:

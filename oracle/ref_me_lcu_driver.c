@@ -59,13 +59,15 @@ enum {
     IP_SEARCH_W, IP_SEARCH_H, IP_NHME_W, IP_NHME_H, IP_L0_TOTAL_W, IP_L0_TOTAL_H,
     IP_L0_W0, IP_L0_W1, IP_L0_H0, IP_L0_H1, IP_L1_W0, IP_L1_W1, IP_L1_H0, IP_L1_H1, IP_L2_W0, IP_L2_W1, IP_L2_H0, IP_L2_H1,
     IP_EN_HME, IP_EN_L0, IP_EN_L1, IP_EN_L2, IP_TWO_LISTS, IP_TEMPORAL_LAYER, IP_HIER_LEVELS, IP_IS_REF, IP_USE_SUBPEL,
-    IP_REF0_POC, IP_REF1_POC, IP_ASM_TYPE, IP_COUNT
+    IP_REF0_POC, IP_REF1_POC, IP_ASM_TYPE, IP_ALL_PU, IP_COUNT
 };
 
 /* planes: [0]=current, [1]=list-0 reference, [2]=list-1 reference; each {full, quarter, sixteenth}.
- * out_sad / out_mv : [n_sb][2][85] ME-buffer order; out_origin: [n_sb][2][4] = x_origin, y_origin (as left in
- * MeContext_t) and two spare; out_res: [n_sb][85][9] = xMvL0,yMvL0,xMvL1,yMvL1, dist0,dir0, dist1,dir1, total.
- * Returns 0, or a negative code. */
+ * ip[IP_ALL_PU] selects the 209-PU mode (pic_depth_mode PIC_ALL_DEPTH_MODE, max_number_of_pus_per_sb 209: the
+ * open_loop_me_fullpel_search_sblock branch of :6745-6813 and bi-prediction over all 209 PUs, :7028); NPU = 209 or 85.
+ * out_sad / out_mv : [n_sb][2][NPU] ME-buffer order; out_origin: [n_sb][2][4] = x_origin, y_origin (as left in
+ * MeContext_t) and two spare; out_res: [n_sb][NPU][11] = xMvL0,yMvL0,xMvL1,yMvL1, dist0,dir0, dist1,dir1, total,
+ * dist2,dir2.  Returns 0, or a negative code. */
 int ref_me_lcu_run(uint8_t **planes, int width, int height, const int32_t *ip, uint32_t *out_sad, uint32_t *out_mv,
                    int32_t *out_origin, int32_t *out_res)
 {
@@ -94,8 +96,9 @@ int ref_me_lcu_run(uint8_t **planes, int width, int height, const int32_t *ip, u
 
     PictureParentControlSet_t *pcs = (PictureParentControlSet_t *)calloc(1, sizeof(*pcs));
     pcs->sequence_control_set_wrapper_ptr = scs_wr;
-    pcs->max_number_of_pus_per_sb = 85;
-    pcs->pic_depth_mode = PIC_SQ_DEPTH_MODE;
+    const int npu = ip[IP_ALL_PU] ? 209 : 85;
+    pcs->max_number_of_pus_per_sb = (uint8_t)npu;
+    pcs->pic_depth_mode = ip[IP_ALL_PU] ? PIC_ALL_DEPTH_MODE : PIC_SQ_DEPTH_MODE;
     pcs->cu8x8_mode = CU_8x8_MODE_0;
     pcs->enable_hme_flag = (EbBool)ip[IP_EN_HME];
     pcs->enable_hme_level0_flag = (EbBool)ip[IP_EN_L0];
@@ -171,18 +174,19 @@ int ref_me_lcu_run(uint8_t **planes, int width, int height, const int32_t *ip, u
             MotionEstimateLcu(pcs, sb_index, sb_origin_x, sb_origin_y, ctx, cur_full);
 
             for (int l = 0; l < 2; l++) {
-                memcpy(out_sad + ((size_t)sb_index * 2 + l) * 85, ctx->p_sb_best_sad[l][0], 85 * 4);
-                memcpy(out_mv + ((size_t)sb_index * 2 + l) * 85, ctx->p_sb_best_mv[l][0], 85 * 4);
+                memcpy(out_sad + ((size_t)sb_index * 2 + l) * npu, ctx->p_sb_best_sad[l][0], (size_t)npu * 4);
+                memcpy(out_mv + ((size_t)sb_index * 2 + l) * npu, ctx->p_sb_best_mv[l][0], (size_t)npu * 4);
                 out_origin[((size_t)sb_index * 2 + l) * 4 + 0] = ctx->x_search_area_origin[l][0];
                 out_origin[((size_t)sb_index * 2 + l) * 4 + 1] = ctx->y_search_area_origin[l][0];
             }
-            for (int pu = 0; pu < 85; pu++) {
+            for (int pu = 0; pu < npu; pu++) {
                 const MeCuResults_t *r = &pcs->me_results[sb_index][pu];
-                int32_t *o = out_res + ((size_t)sb_index * 85 + pu) * 9;
+                int32_t *o = out_res + ((size_t)sb_index * npu + pu) * 11;
                 o[0] = r->xMvL0; o[1] = r->yMvL0; o[2] = r->xMvL1; o[3] = r->yMvL1;
                 o[4] = (int32_t)r->distortionDirection[0].distortion; o[5] = r->distortionDirection[0].direction;
                 o[6] = (int32_t)r->distortionDirection[1].distortion; o[7] = r->distortionDirection[1].direction;
                 o[8] = r->totalMeCandidateIndex;
+                o[9] = (int32_t)r->distortionDirection[2].distortion; o[10] = r->distortionDirection[2].direction;
             }
         }
     return 0;

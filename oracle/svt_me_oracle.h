@@ -90,6 +90,20 @@ void orc_bipred_pack_batch(const uint8_t *src_plane, uint32_t src_stride, const 
                            uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
                            int n_lists, int bipred_8x8, svthip_me_cu_result *out);
 
+/* ---- the 209-PU (all-partition) mode ---- */
+/* [209][5] = w, h, px, py, ME-buffer index, by raster PU index */
+void orc_pu_geometry209(uint8_t *out);
+void orc_subpel_refine_209pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                             int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                             uint32_t *best_mv);
+void orc_subpel_refine209_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
+                                const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv);
+/* orc_bipred_pack_batch over [n_sb][n_pu] arrays, n_pu = 85 or 209 */
+void orc_bipred_pack_batch_npu(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref0_plane, uint32_t ref0_stride,
+                               const int32_t *desc0, const uint8_t *ref1_plane, uint32_t ref1_stride, const int32_t *desc1,
+                               uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
+                               int n_lists, int bipred_8x8, int n_pu, svthip_me_cu_result *out);
+
 /* ---- transform / quantisation (oracle/svt_tq_oracle.c) ---- */
 /* aom_quantize_b{,_32x32,_64x64}_c_II (highbd = 0) / aom_highbd_quantize_b*_c (highbd = 1), flat qmatrix.
  * qp = {zbin[2], round[2], quant[2], quant_shift[2], dequant[2]} */

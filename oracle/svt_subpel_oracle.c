@@ -259,6 +259,87 @@ void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, cons
 }
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Geometry of the 209 PUs of the all-partition mode (pic_depth_mode <= PIC_ALL_C_DEPTH_MODE).
+ *
+ * me_results / BiPredictionCompensation index PUs in RASTER order within each shape class (partitionWidth /
+ * partitionHeight / puSearchIndexMap, Codec/EbMotionEstimation.h:177-322); the ME buffers (p_sb_best_sad / _mv) hold
+ * each class in the order ExtSadCalculation* fills it (z-order of the constituent squares), and HalfPelSearch_LCU /
+ * QuarterPelSearch_LCU / the packing loop translate with tab16x16 .. tab8x32 (EbMotionEstimation.h:89-171).  The maps
+ * are DERIVED here from the buffer order the full-pel stage produces (orc_fullpel_search_209pu above, itself pinned)
+ * rather than restated as tables; tests/test_hme_vs_ref.py checks the result against the reference's own
+ * MotionEstimateLcu run in 209-PU mode.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct { uint8_t w, h, px, py; uint8_t me; } PuGeom; /* indexed by raster PU index; me = ME-buffer index */
+
+static int z4(int col, int row) { return ((row >> 1) * 2 + (col >> 1)) * 4 + (row & 1) * 2 + (col & 1); } /* 4x4 grid z-order */
+
+static const PuGeom *pu_geom209(void)
+{
+    static PuGeom g[209];
+    static int ready = 0;
+    if (ready) return g;
+    /* class: base, count, w, h, columns */
+    static const int cls[14][5] = {{0, 1, 64, 64, 1},   {1, 4, 32, 32, 2},   {5, 16, 16, 16, 4},  {21, 64, 8, 8, 8},  {85, 2, 64, 32, 1},
+                                   {87, 8, 32, 16, 2},  {95, 32, 16, 8, 4},  {127, 2, 32, 64, 2}, {129, 8, 16, 32, 4}, {137, 32, 8, 16, 8},
+                                   {169, 16, 32, 8, 2}, {185, 16, 8, 32, 8}, {201, 4, 64, 16, 1}, {205, 4, 16, 64, 4}};
+    for (int c = 0; c < 14; c++)
+        for (int p = 0; p < cls[c][1]; p++) {
+            const int base = cls[c][0], w = cls[c][2], h = cls[c][3], col = p % cls[c][4], row = p / cls[c][4];
+            int i;
+            switch (base) {
+            case 5: i = z4(col, row); break;                                              /* 16x16: z-order */
+            case 21: i = 4 * z4(col >> 1, row >> 1) + (row & 1) * 2 + (col & 1); break;   /* 8x8: raster inside its 16x16 */
+            case 87: i = 2 * ((row >> 1) * 2 + col) + (row & 1); break;                   /* 32x16: (quadrant, upper/lower) */
+            case 95: i = 2 * z4(col, row >> 1) + (row & 1); break;                        /* 16x8: (16x16 z, upper/lower) */
+            case 137: i = 2 * z4(col >> 1, row) + (col & 1); break;                       /* 8x16: (16x16 z, left/right) */
+            case 169: i = 4 * ((row >> 2) * 2 + col) + (row & 3); break;                  /* 32x8: (quadrant, row of 8) */
+            default: i = p; break; /* 64x64, 32x32, 64x32, 32x64, 16x32, 8x32, 64x16, 16x64: buffer order = raster */
+            }
+            g[base + p] = (PuGeom){(uint8_t)w, (uint8_t)h, (uint8_t)(col * w), (uint8_t)(row * h), (uint8_t)(base + i)};
+        }
+    ready = 1;
+    return g;
+}
+
+/* [209][5] = w, h, px, py, ME-buffer index, by raster PU index (for the tests) */
+void orc_pu_geometry209(uint8_t *out)
+{
+    const PuGeom *g = pu_geom209();
+    for (int i = 0; i < 209; i++) { out[5 * i] = g[i].w; out[5 * i + 1] = g[i].h; out[5 * i + 2] = g[i].px; out[5 * i + 3] = g[i].py; out[5 * i + 4] = g[i].me; }
+}
+
+/* Sub-pel refinement of all 209 PUs of one SB against one list: the 85 squares as above, then the rectangular PUs
+ * (HalfPelSearch_LCU :2418-2786, QuarterPelSearch_LCU :3580-4114; every PU is refined independently, so the order of
+ * the calls does not matter).  Arrays are [209] in ME-buffer order.  Same pinning status as the 85-PU function. */
+void orc_subpel_refine_209pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                             int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                             uint32_t *best_mv)
+{
+    orc_subpel_refine_85pu(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, best_sad, best_mv, 0, 0);
+    RefView r = {ref00, (int)ref_stride};
+    const PuGeom *g = pu_geom209();
+    for (int pu = 85; pu < 209; pu++) {
+        const int n = g[pu].me;
+        uint32_t ssd = 0;
+        uint8_t dir = 0;
+        pu_half_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, &best_sad[n],
+                    &best_mv[n], &ssd, &dir);
+        pu_quarter_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, &best_sad[n],
+                       &best_mv[n], &ssd, dir);
+    }
+}
+
+void orc_subpel_refine209_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
+                                const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv)
+{
+    for (uint32_t i = 0; i < n_sb; i++) {
+        const int32_t *d = desc + 6 * i;
+        orc_subpel_refine_209pu(src_plane + d[0], src_stride, ref_plane + d[1], ref_stride, (int16_t)d[2], (int16_t)d[3], disable_8x8,
+                                best_sad + 209 * i, best_mv + 209 * i);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------
  * Bi-prediction SAD and result packing (Codec/EbMotionEstimation.c:6973-7146, BiPredictionSearch :5261-5342,
  * BiPredictionCompensation :5090-5254, BiPredAverging :4933-5081, SelectBuffer :4762-4815,
  * QuarterPelCompensation :4818-4920, Sort3Elements :5434-5463).
@@ -311,35 +392,24 @@ static uint32_t bipred_sad(const uint8_t *src, int ss, const RefView *r0, int xo
     return sad;
 }
 
-/* raster PU index (me_results order) -> ME-buffer index (:6980-7015), square PUs only */
-static int me_index(int pu)
-{
-    if (pu > 20) return kTab8[pu - 21] + 21;
-    if (pu > 4) return kTab16[pu - 5] + 5;
-    return pu;
-}
-
-/* n_lists = 1 (P) or 2 (B).  sad/mv arrays are ME-buffer ordered [85]; out = 85 svthip_me_cu_result in raster PU order.
- * bipred_8x8 = (cu8x8_mode == CU_8x8_MODE_0): 8x8 PUs get a bi-pred candidate too (:7028). */
-void orc_bipred_pack_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref0_00, uint32_t ref0_stride, int16_t xo0,
-                          int16_t yo0, const uint8_t *ref1_00, uint32_t ref1_stride, int16_t xo1, int16_t yo1,
-                          const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1, int n_lists,
-                          int bipred_8x8, svthip_me_cu_result *out)
+/* n_lists = 1 (P) or 2 (B).  n_pu = 85 or 209.  sad/mv arrays are ME-buffer ordered [n_pu]; out = n_pu svthip_me_cu_result
+ * in raster PU order (ME-buffer index per raster PU: :6980-7015).
+ * bipred_8x8 = (cu8x8_mode == CU_8x8_MODE_0): 8x8 PUs get a bi-pred candidate too; in the 209-PU mode every PU gets one
+ * whatever cu8x8_mode is (:7028). */
+static void bipred_pack_sb(const uint8_t *src, uint32_t src_stride, const uint8_t *ref0_00, uint32_t ref0_stride, int16_t xo0, int16_t yo0,
+                           const uint8_t *ref1_00, uint32_t ref1_stride, int16_t xo1, int16_t yo1, const uint32_t *sad0,
+                           const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1, int n_lists, int bipred_8x8, int n_pu,
+                           svthip_me_cu_result *out)
 {
     RefView r0 = {ref0_00, (int)ref0_stride}, r1 = {ref1_00, (int)ref1_stride};
-    for (int pu = 0; pu < 85; pu++) {
-        const int n = me_index(pu);
-        const int w = pu == 0 ? 64 : pu < 5 ? 32 : pu < 21 ? 16 : 8;
-        int px, py;
-        if (pu == 0) { px = py = 0; }
-        else if (pu < 5) { px = ((pu - 1) & 1) << 5; py = ((pu - 1) >> 1) << 5; }
-        else if (pu < 21) { px = ((pu - 5) & 3) << 4; py = ((pu - 5) >> 2) << 4; }
-        else { px = ((pu - 21) & 7) << 3; py = ((pu - 21) >> 3) << 3; }
+    const PuGeom *g = pu_geom209();
+    for (int pu = 0; pu < n_pu; pu++) {
+        const int n = g[pu].me;
         svthip_me_cu_result *o = &out[pu];
         int total = n_lists;
         uint32_t bi = 0;
-        if (n_lists == 2 && (bipred_8x8 || pu < 21)) {
-            bi = bipred_sad(src, (int)src_stride, &r0, xo0, yo0, mv0[n], &r1, xo1, yo1, mv1[n], px, py, w, w);
+        if (n_lists == 2 && (bipred_8x8 || pu < 21 || n_pu == 209)) {
+            bi = bipred_sad(src, (int)src_stride, &r0, xo0, yo0, mv0[n], &r1, xo1, yo1, mv1[n], g[pu].px, g[pu].py, g[pu].w, g[pu].h);
             total = 3;
         }
         o->xMvL0 = (int16_t)(mv0[n] & 0xffff);
@@ -365,6 +435,29 @@ void orc_bipred_pack_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t
             o->distortion[0] = a;
             o->direction[0] = 0;
         }
+    }
+}
+
+void orc_bipred_pack_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref0_00, uint32_t ref0_stride, int16_t xo0,
+                          int16_t yo0, const uint8_t *ref1_00, uint32_t ref1_stride, int16_t xo1, int16_t yo1,
+                          const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1, int n_lists,
+                          int bipred_8x8, svthip_me_cu_result *out)
+{
+    bipred_pack_sb(src, src_stride, ref0_00, ref0_stride, xo0, yo0, ref1_00, ref1_stride, xo1, yo1, sad0, mv0, sad1, mv1, n_lists, bipred_8x8, 85, out);
+}
+
+/* the same over [n_sb][n_pu] arrays, n_pu = 85 or 209 */
+void orc_bipred_pack_batch_npu(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref0_plane, uint32_t ref0_stride,
+                               const int32_t *desc0, const uint8_t *ref1_plane, uint32_t ref1_stride, const int32_t *desc1,
+                               uint32_t n_sb, const uint32_t *sad0, const uint32_t *mv0, const uint32_t *sad1, const uint32_t *mv1,
+                               int n_lists, int bipred_8x8, int n_pu, svthip_me_cu_result *out)
+{
+    for (uint32_t i = 0; i < n_sb; i++) {
+        const int32_t *d0 = desc0 + 6 * i, *d1 = n_lists == 2 ? desc1 + 6 * i : d0;
+        bipred_pack_sb(src_plane + d0[0], src_stride, ref0_plane + d0[1], ref0_stride, (int16_t)d0[2], (int16_t)d0[3],
+                       (n_lists == 2 ? ref1_plane : ref0_plane) + d1[1], n_lists == 2 ? ref1_stride : ref0_stride, (int16_t)d1[2],
+                       (int16_t)d1[3], sad0 + (size_t)n_pu * i, mv0 + (size_t)n_pu * i, n_lists == 2 ? sad1 + (size_t)n_pu * i : sad0 + (size_t)n_pu * i,
+                       n_lists == 2 ? mv1 + (size_t)n_pu * i : mv0 + (size_t)n_pu * i, n_lists, bipred_8x8, n_pu, out + (size_t)n_pu * i);
     }
 }
 

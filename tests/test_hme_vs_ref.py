@@ -112,3 +112,75 @@ def test_hme_disabled_levels(oracle, refme):
             d, s, m = mine[l]
             assert np.array_equal(d[:, 2:4], ref["origin"][:, l]), (flags, l)
             assert np.array_equal(s, ref["sad"][:, l]) and np.array_equal(m, ref["mv"][:, l]), (flags, l)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 209-PU (all-partition) mode: the reference's MotionEstimateLcu with pic_depth_mode = PIC_ALL_DEPTH_MODE
+# ---------------------------------------------------------------------------------------------------------------------
+def oracle_chain209(oracle, pics, P, two_lists):
+    pool, descs = svtav1_hip.build_picture_pool(pics)
+    sb = svtav1_hip.sb_origins(pics[0].width, pics[0].height)
+    out = {}
+    state = np.zeros((sb.shape[0], 25), np.int16)
+    d0, _ = oracle.hme_search_center_batch(pool, descs[0], descs[1], P, 0, sb, None, state)
+    s0, m0 = oracle.fullpel_search209_batch(pool, pool, d0, descs[0].full_stride, descs[1].full_stride)
+    out[0] = (d0, s0, m0)
+    if two_lists:
+        d1, _ = oracle.hme_search_center_batch(pool, descs[0], descs[2], P, 1, sb, m0[:, 0], state)
+        s1, m1 = oracle.fullpel_search209_batch(pool, pool, d1, descs[0].full_stride, descs[2].full_stride)
+        out[1] = (d1, s1, m1)
+    return out
+
+
+CASES209 = [CASES[0], CASES[2], CASES[5], CASES[6], CASES[8]]
+
+
+@pytest.mark.parametrize("case", CASES209)
+def test_209pu_mode_matches_reference_motion_estimate_lcu(oracle, refme, case):
+    """HME + open_loop_me_fullpel_search_sblock (the reference's static 209-PU caller, :1556) + bi-prediction at integer MVs
+    over all 209 PUs + packing through tab32x16 .. tab8x32, against the oracle chain."""
+    w, h, kind, hier, tl, two, is_ref, poc_eq = case
+    pics = _pics(w, h, kind)
+    P = svtav1_hip.default_me_params(w, h, hier, tl, is_ref, poc_eq)
+    ref = refme.run(pics[0], pics[1], pics[2], P, two_lists=two, hierarchical_levels=hier, all_pu=True)
+    mine = oracle_chain209(oracle, pics, P, two)
+    for l in mine:
+        d, s, m = mine[l]
+        assert np.array_equal(d[:, 2:4], ref["origin"][:, l]), f"list {l}: search-area origins differ"
+        assert np.array_equal(s, ref["sad"][:, l]), f"list {l}: SADs differ"
+        assert np.array_equal(m, ref["mv"][:, l]), f"list {l}: MVs differ"
+    pool, descs = svtav1_hip.build_picture_pool(pics)
+    fs = descs[0].full_stride
+    if two:
+        res = oracle.bipred_pack_batch(pool, fs, pool, fs, mine[0][0], mine[0][1], mine[0][2], pool, fs, mine[1][0], mine[1][1], mine[1][2],
+                                       n_pu=209)
+    else:
+        res = oracle.bipred_pack_batch(pool, fs, pool, fs, mine[0][0], mine[0][1], mine[0][2], n_pu=209)
+    r = ref["res"]  # [n,209,11] = xMvL0,yMvL0,xMvL1,yMvL1, dist0,dir0, dist1,dir1, total, dist2,dir2
+    assert np.array_equal(res["totalMeCandidateIndex"], r[:, :, 8])
+    assert np.array_equal(res["xMvL0"], r[:, :, 0]) and np.array_equal(res["yMvL0"], r[:, :, 1])
+    ncand = 3 if two else 1
+    for k, (di, dr) in enumerate(((4, 5), (6, 7), (9, 10))[:ncand]):
+        assert np.array_equal(res["distortion"][:, :, k], r[:, :, di].astype(np.uint32)), f"distortion[{k}]"
+        assert np.array_equal(res["direction"][:, :, k], r[:, :, dr]), f"direction[{k}]"
+    if two:
+        assert np.array_equal(res["xMvL1"], r[:, :, 2]) and np.array_equal(res["yMvL1"], r[:, :, 3])
+
+
+def test_pu_geometry209_consistent_with_fullpel(oracle):
+    """The derived raster -> ME-buffer map and PU rectangles: at a single search position the 209-PU full-pel SAD of buffer entry
+    n must be the (row-subsampled) SAD over exactly the rectangle the geometry table gives for it."""
+    g = oracle.pu_geometry209()
+    assert sorted(g[:, 4].tolist()) == list(range(209))
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    ref = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    desc = np.array([[0, 0, 0, 0, 1, 1]], np.int32)
+    sad, _ = oracle.fullpel_search209_batch(src, ref, desc)
+    ad = np.abs(src.astype(np.int32) - ref.astype(np.int32))
+    for pu in range(209):
+        w, h, px, py, n = (int(v) for v in g[pu])
+        blk = ad[py:py + h, px:px + w]
+        # 8x8 SADs are computed on the even rows and doubled (ExtSadCalculation_8x8_16x16); everything else is a sum of them
+        want = 2 * int(blk[0::2].sum())
+        assert int(sad[0, n]) == want, (pu, n, w, h, px, py)
