@@ -379,12 +379,40 @@ int32_t svthip_encode_tu16_batch_dev(svthip_ctx *ctx, const uint16_t *d_src, con
  * (Source/Lib/Codec/EbMotionEstimation.c:1556-1595, :1065-1231, :159-1052): the 85 square PUs plus the 124 rectangular ones
  * (64x32, 32x16, 16x8, 32x64, 16x32, 8x16, 32x8, 8x32, 64x16, 16x64), d_best_sad / d_best_mv = [n_sb][209] in the reference's
  * ME-buffer order (Codec/EbMotionEstimationContext.h:42-265), including the reference's stale-variable update of PU 92
- * (32x16[5], :343-347).  Same descriptors and window rules as svthip_me_fullpel_search_dev.  Sub-pel refinement and
- * bi-prediction of the rectangular PUs are not built yet. */
+ * (32x16[5], :343-347).  Same descriptors and window rules as svthip_me_fullpel_search_dev. */
 int32_t svthip_me_fullpel_search209_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
                                         const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
                                         uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
                                         uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
+/* Sub-pel refinement of all 209 PUs: svthip_me_subpel_refine_dev's squares plus the rectangular half of HalfPelSearch_LCU
+ * (Source/Lib/Codec/EbMotionEstimation.c:2418-2786) and of QuarterPelSearch_LCU (:3580-4114).  d_best_sad / d_best_mv =
+ * [n_sb][209] in ME-buffer order, refined in place; every other argument as in svthip_me_subpel_refine_dev. */
+int32_t svthip_me_subpel_refine209_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                       const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
+                                       uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                       int32_t disable_8x8_refinement, uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
+/* Bi-prediction search and result packing over all 209 PUs (the loop of MotionEstimateLcu :6973-7146 with
+ * max_number_of_pus_per_sb = 209; BiPredictionSearch :5261-5342 uses partitionWidth / partitionHeight / puSearchIndexMap,
+ * Codec/EbMotionEstimation.h:177-322).  In this mode every PU gets a bi-prediction candidate whatever cu8x8_mode is
+ * (:7028).  d_sad* / d_mv* = [n_sb][209] in ME-buffer order; d_out = [n_sb][209] in raster PU order (me_results), the
+ * translation between the two being tab16x16 .. tab8x32 (EbMotionEstimation.h:89-171). */
+int32_t svthip_me_bipred_pack209_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                     const uint8_t *d_ref0_plane, uint32_t ref0_stride, const svthip_fullpel_desc *d_desc0,
+                                     const uint8_t *d_ref1_plane, uint32_t ref1_stride, const svthip_fullpel_desc *d_desc1,
+                                     uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                     const uint32_t *d_sad0, const uint32_t *d_mv0, const uint32_t *d_sad1, const uint32_t *d_mv1,
+                                     uint32_t n_lists, svthip_me_cu_result *d_out, void *stream);
+
+/* MotionEstimateLcu (:6152) in the 209-PU mode for a batch of pictures: svthip_motion_estimate_batch_dev with the 209-PU
+ * full-pel search, sub-pel refinement and bi-prediction.  d_out = [n_jobs][n_sb][209]; the optional d_list_sad /
+ * d_list_mv = [2][n_jobs * n_sb][209]. */
+int32_t svthip_motion_estimate209_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                            const svthip_pa_picture *ref0, const svthip_pa_picture *ref1, uint32_t n_jobs,
+                                            const svthip_me_params *params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                            const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
+                                            uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
 
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */

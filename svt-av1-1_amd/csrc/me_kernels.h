@@ -34,14 +34,26 @@ __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable 
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                 const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
-                                int disable_8x8, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv);
+                                int disable_8x8, int pu_stride, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv);
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
+__global__ void subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
+                                  uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
+                                  uint32_t* __restrict__ io_mv);
+size_t subpel_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh);
+__global__ void bipred_nsq_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                       const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride, const int32_t* __restrict__ desc0,
+                                       const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride, const int32_t* __restrict__ desc1,
+                                       const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,
+                                       const uint32_t* __restrict__ sad1, const uint32_t* __restrict__ mv1, int n_lists, int win_bytes,
+                                       const uint32_t* __restrict__ bisad_sq, svthip_me_cu_result* __restrict__ out);
+size_t bipred_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void bipred_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                    const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride, const int32_t* __restrict__ desc0,
                                    const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride, const int32_t* __restrict__ desc1,
                                    const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,
                                    const uint32_t* __restrict__ sad1, const uint32_t* __restrict__ mv1, int n_lists, int bipred_8x8,
-                                   int win_bytes, svthip_me_cu_result* __restrict__ out);
+                                   int win_bytes, int pu_stride, uint32_t* __restrict__ bisad_out,
+                                   svthip_me_cu_result* __restrict__ out);
 size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh);
 size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 

@@ -149,45 +149,43 @@ struct Win {
     __device__ __forceinline__ int at(int x, int y) const { return p[(y + kMargin) * pitch + x + kMargin]; }
 };
 
-// Per-PU tiles, TW = W + 4 wide; tile coordinate (0,0) = search-region (bx - 2, by - 2).
+// Per-PU tiles of a W x H PU, TW = W + 4 wide; tile coordinate (0,0) = search-region (bx - 2, by - 2).
 // bt: b plane with 2 extra rows above and below (rows by-4 .. by+H+3) so j can be filtered from it.
-template <int W>
+template <int W, int H = W>
 struct Tiles {
-    static constexpr int TW = W + 4;
-    lds_u8* bt;  // [W + 8][TW]
-    lds_u8* ht;  // [W + 4][TW]
-    lds_u8* jt;  // [W + 4][TW]
-    static constexpr int bytes = TW * (W + 8) + 2 * TW * (W + 4);
-    __device__ __forceinline__ int b(int tx, int ty) const { return bt[(ty + 2) * TW + tx]; }
-    __device__ __forceinline__ int h(int tx, int ty) const { return ht[ty * TW + tx]; }
-    __device__ __forceinline__ int j(int tx, int ty) const { return jt[ty * TW + tx]; }
+    static constexpr int TW = W + 4, TPW = W, TPH = H;
+    lds_u8* bt;  // [H + 8][TW]
+    lds_u8* ht;  // [H + 4][TW]
+    lds_u8* jt;  // [H + 4][TW]
+    static constexpr int bytes = TW * (H + 8) + 2 * TW * (H + 4);
+    static __device__ __forceinline__ Tiles at(lds_u8* b) { return Tiles{b, b + TW * (H + 8), b + TW * (H + 8) + TW * (H + 4)}; }
 };
 
 // tile memory of a workgroup: one 64x64 set, one 32x32 set, kGroups16 16x16 sets, kGroups8 8x8 sets
 constexpr int kPredBytes = 4096 + 1024 + kGroups16 * 256 + kGroups8 * 64;  // list-0 predictions of the bi-pred kernel
 constexpr int kTileBytes = (Tiles<64>::bytes + Tiles<32>::bytes + kGroups16 * Tiles<16>::bytes + kGroups8 * Tiles<8>::bytes + 15) & ~15;
 
-template <int W>
-__device__ __forceinline__ uint32_t plane_sample4(const Win& win, const Tiles<W>& t, int plane, int x, int y, int bx, int by)
+template <class T>
+__device__ __forceinline__ uint32_t plane_sample4(const Win& win, const T& t, int plane, int x, int y, int bx, int by)
 {
-    // 4 horizontally consecutive samples starting at search-region (x,y); tiles cover [bx-2, bx+W+2) x [by-2, by+W+2).
+    // 4 horizontally consecutive samples starting at search-region (x,y); tiles cover [bx-2, bx+W+2) x [by-2, by+H+2).
     // One address computation for the four planes: the plane index is uniform within a lane group but may differ between
     // the groups of a wave.
     const int tx = x - (bx - 2), ty = y - (by - 2);
     const lds_u8* base = plane == 0 ? win.p : (plane == 1 ? (const lds_u8*)t.bt : (plane == 2 ? (const lds_u8*)t.ht : (const lds_u8*)t.jt));
-    const int pitch = plane == 0 ? win.pitch : Tiles<W>::TW;
+    const int pitch = plane == 0 ? win.pitch : T::TW;
     const int cx = plane == 0 ? x + kMargin : tx;
     const int cy = plane == 0 ? y + kMargin : (plane == 1 ? ty + 2 : ty);
     return lds_u32_at(base + cy * pitch + cx);
 }
 
-// Fill the b / h / j tiles of a W x W PU whose full-pel block sits at search-region (bx,by).
-template <int W, int LPP>
-__device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
+// Fill the b / h / j tiles of a W x H PU whose full-pel block sits at search-region (bx,by).
+template <class T, int LPP>
+__device__ void fill_tiles(const Win& win, T& t, int bx, int by, int l)
 {
-    constexpr int TW = Tiles<W>::TW, TW4 = TW / 4;  // a lane produces 4 horizontally consecutive samples per step
+    constexpr int TW = T::TW, TW4 = TW / 4, H = T::TPH;  // a lane produces 4 horizontally consecutive samples per step
     const int x0 = bx - 2;
-    for (int i = l; i < TW4 * (W + 8); i += LPP) {  // b rows by-4 .. by+W+3
+    for (int i = l; i < TW4 * (H + 8); i += LPP) {  // b rows by-4 .. by+H+3
         const int r = i / TW4, c = 4 * (i - r * TW4);
         const lds_u8* p = win.p + (by - 4 + r + kMargin) * win.pitch + (x0 + c - 2 + kMargin);  // 7 input bytes from here
         const uint32_t a = (uint32_t)reinterpret_cast<uintptr_t>(p);
@@ -199,7 +197,7 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
         *reinterpret_cast<lds_u32*>(t.bt + r * TW + c) = o;
     }
 #pragma unroll 2
-    for (int i = l; i < TW4 * (W + 4); i += LPP) {  // h rows by-2 .. by+W+1
+    for (int i = l; i < TW4 * (H + 4); i += LPP) {  // h rows by-2 .. by+H+1
         const int r = i / TW4, c = 4 * (i - r * TW4);
         const lds_u8* p = win.p + (by - 2 + r - 2 + kMargin) * win.pitch + (x0 + c + kMargin);  // rows y-2 .. y+1
         *reinterpret_cast<lds_u32*>(t.ht + r * TW + c) =
@@ -208,7 +206,7 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 2
-    for (int i = l; i < TW4 * (W + 4); i += LPP) {  // j from the rounded b: tile row r <- b tile rows r .. r+3
+    for (int i = l; i < TW4 * (H + 4); i += LPP) {  // j from the rounded b: tile row r <- b tile rows r .. r+3
         const int r = i / TW4, c = 4 * (i - r * TW4);
         const lds_u32* q = reinterpret_cast<const lds_u32*>(t.bt + r * TW + c);
         *reinterpret_cast<lds_u32*>(t.jt + r * TW + c) = vfilt4(q[0], q[TW4], q[2 * TW4], q[3 * TW4]);
@@ -217,10 +215,10 @@ __device__ void fill_tiles(const Win& win, Tiles<W>& t, int bx, int by, int l)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// One PU (PW x PW pixels at (px,py) in the SB; tiles sized for TWd >= PW) per group of LPP consecutive lanes, l = lane
+// One PU (PW x PH pixels at (px,py) in the SB; tiles T at least that large) per group of LPP consecutive lanes, l = lane
 // within the group.  All lanes of a group return the same updated sad / mv / ssd / dir.
-template <int PW, int TWd, int LPP>
-__device__ void half_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by,
+template <int PW, int PH, class T, int LPP>
+__device__ void half_pel_pu(const lds_u8* src, const Win& win, const T& t, int px, int py, int bx, int by,
                             int x_mv, int y_mv, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int& dir)
 {
     // candidate k: plane, dx, dy  (L, R, T, B, TL, TR, BR, BL)
@@ -229,9 +227,9 @@ __device__ void half_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>&
     for (int k = 0; k < 9; k++) ssd[k] = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) sad[k] = 0;
-    constexpr int TW = Tiles<TWd>::TW, PW4 = PW / 4;
+    constexpr int TW = T::TW, PW4 = PW / 4;
 #pragma unroll 2
-    for (int i = l; i < PW4 * PW; i += LPP) {  // 4 pixels per step
+    for (int i = l; i < PW4 * PH; i += LPP) {  // 4 pixels per step
         const int y = i / PW4, x = 4 * (i - y * PW4);
         const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
         // tile samples of pixel x sit at tile column x + 2: rows are 4-byte aligned, so L / R candidates are the two
@@ -274,8 +272,8 @@ __device__ void half_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>&
         : (m == ssd[4]) ? DIR_TL : (m == ssd[5]) ? DIR_TR : (m == ssd[7]) ? DIR_BL : DIR_BR;
 }
 
-template <int PW, int TWd, int LPP>
-__device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TWd>& t, int px, int py, int bx, int by, int xo,
+template <int PW, int PH, class T, int LPP>
+__device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const T& t, int px, int py, int bx, int by, int xo,
                                int yo, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int d)
 {
     const int x_mv = (int)(int16_t)(best_mv & 0xffffu), y_mv = (int)(int16_t)(best_mv >> 16);
@@ -317,11 +315,11 @@ __device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TW
         const int qdx = (int)((0x2858u >> (2 * k)) & 3u) - 1, qdy = (int)((0xA085u >> (2 * k)) & 3u) - 1;
         uint32_t ssd = 0, sad = 0;
 #pragma unroll 2
-        for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
+        for (int i = l; i < (PW / 4) * PH; i += LPP) {  // 4 pixels per step
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
             const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
-            const uint32_t a = plane_sample4<TWd>(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
-            const uint32_t b = plane_sample4<TWd>(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
+            const uint32_t a = plane_sample4(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
+            const uint32_t b = plane_sample4(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
             const uint32_t v = avg_u8x4(a, b);
             ssd = ssd4(s4, v, ssd);  // CombinedAveragingSSD: true SSD (:2792-2817)
             sad = __builtin_amdgcn_sad_u8(s4, v, sad);
@@ -336,21 +334,21 @@ __device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const Tiles<TW
     }
 }
 
-// half + quarter for one PU of size PW at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
-template <int PW, int LPP>
-__device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW>& t, int px, int py, int xo, int yo, int l,
+// half + quarter for one PW x PH PU at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
+template <int PW, int PH, int LPP>
+__device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW, PH>& t, int px, int py, int xo, int yo, int l,
                           uint32_t* sad_io, uint32_t* mv_io, int pu)
 {
     uint32_t bs = sad_io[pu], bm = mv_io[pu], bssd = 0;
     const int x_mv = (int)(int16_t)(bm & 0xffffu), y_mv = (int)(int16_t)(bm >> 16);
     const int bx = (x_mv >> 2) - xo + px, by = (y_mv >> 2) - yo + py;
-    fill_tiles<PW, LPP>(win, t, bx, by, l);
+    fill_tiles<Tiles<PW, PH>, LPP>(win, t, bx, by, l);
     int dir = 0;
-    half_pel_pu<PW, PW, LPP>(src, win, t, px, py, bx, by, x_mv, y_mv, l, bs, bm, bssd, dir);
-    if (PW == 64)  // the 64x64 PU is quarter-pel refined on a 32x32 block at the SB origin (:3395-3409)
-        quarter_pel_pu<32, PW, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
+    half_pel_pu<PW, PH, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, x_mv, y_mv, l, bs, bm, bssd, dir);
+    if (PW == 64 && PH == 64)  // the 64x64 PU is quarter-pel refined on a 32x32 block at the SB origin (:3395-3409)
+        quarter_pel_pu<32, 32, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
     else
-        quarter_pel_pu<PW, PW, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
+        quarter_pel_pu<PW, PH, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
     if (l == 0) {
         sad_io[pu] = bs;
         mv_io[pu] = bm;
@@ -361,7 +359,7 @@ __device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW>& t, int p
 
 __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                        const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
-                                                       const int32_t* __restrict__ desc, int disable_8x8,
+                                                       const int32_t* __restrict__ desc, int disable_8x8, int pu_stride,
                                                        uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -405,29 +403,29 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     __syncthreads();
 
     Win win{wbuf, pitch};
-    uint32_t* sad_io = io_sad + (size_t)85 * blockIdx.x;
-    uint32_t* mv_io = io_mv + (size_t)85 * blockIdx.x;
+    uint32_t* sad_io = io_sad + (size_t)pu_stride * blockIdx.x;  // [n_sb][pu_stride], the squares are entries 0..84
+    uint32_t* mv_io = io_mv + (size_t)pu_stride * blockIdx.x;
 
     if (wave == 0) {
         Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-        refine_pu<64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
+        refine_pu<64, 64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
     } else if (wave == 1) {
         lds_u8* b = tile_base + t64;
         Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
-        for (int p = 0; p < 4; p++) refine_pu<32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
+        for (int p = 0; p < 4; p++) refine_pu<32, 32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
     } else if (wave == 2) {
         lds_u8* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
         Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
         for (int pass = 0; pass < 4; pass++) {
             const int p = pass * 4 + (lane >> 4);
-            refine_pu<16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p]);
+            refine_pu<16, 16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p]);
         }
     } else if (!disable_8x8) {
         lds_u8* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
         Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
         for (int pass = 0; pass < 8; pass++) {
             const int p = pass * 8 + (lane >> 3);
-            refine_pu<8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p]);
+            refine_pu<8, 8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p]);
         }
     }
 }
@@ -450,18 +448,18 @@ __device__ const uint8_t kBiFrac[16][2] = {
     {BS(2, 0, 1), BS(0, 0, 1)}, {BS(2, 0, 1), BS(1, 1, 1)}, {BS(3, 1, 1), BS(1, 1, 1)}, {BS(2, 1, 1), BS(1, 1, 1)}};
 #undef BS
 
-template <int TWd>
-__device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const Tiles<TWd>& t, int e0, int e1, int x, int y, int bx, int by)
+template <class T>
+__device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const T& t, int e0, int e1, int x, int y, int bx, int by)
 {
-    const uint32_t a = plane_sample4<TWd>(win, t, e0 & 3, x + ((e0 >> 2) & 1), y + ((e0 >> 3) & 1), bx, by);
-    const uint32_t b = plane_sample4<TWd>(win, t, e1 & 3, x + ((e1 >> 2) & 1), y + ((e1 >> 3) & 1), bx, by);
+    const uint32_t a = plane_sample4(win, t, e0 & 3, x + ((e0 >> 2) & 1), y + ((e0 >> 3) & 1), bx, by);
+    const uint32_t b = plane_sample4(win, t, e1 & 3, x + ((e1 >> 2) & 1), y + ((e1 >> 3) & 1), bx, by);
     return avg_u8x4(a, b);
 }
 
-// bi-pred SAD of one PU per group of LPP lanes: list-0 prediction goes through `pred0` (PW*PW bytes of LDS per group) so the
-// tile memory can be reused for list 1
-template <int PW, int LPP>
-__device__ uint32_t bipred_pu(const lds_u8* src, const Win& win0, const Win& win1, Tiles<PW>& t, lds_u8* pred0, int px, int py,
+// bi-pred SAD of one PW x PH PU per group of LPP lanes: list-0 prediction goes through `pred0` (PW*PH bytes of LDS per group)
+// so the tile memory can be reused for list 1
+template <int PW, int PH, int LPP>
+__device__ uint32_t bipred_pu(const lds_u8* src, const Win& win0, const Win& win1, Tiles<PW, PH>& t, lds_u8* pred0, int px, int py,
                               uint32_t mv0, int xo0, int yo0, uint32_t mv1, int xo1, int yo1, int l)
 {
     const int x0 = (int)(int16_t)(mv0 & 0xffffu), y0 = (int)(int16_t)(mv0 >> 16);
@@ -469,25 +467,25 @@ __device__ uint32_t bipred_pu(const lds_u8* src, const Win& win0, const Win& win
     const int f0 = (x0 & 3) + ((y0 & 3) << 2), f1 = (x1 & 3) + ((y1 & 3) << 2);
     const int bx0 = (x0 >> 2) - xo0 + px, by0 = (y0 >> 2) - yo0 + py;
     const int bx1 = (x1 >> 2) - xo1 + px, by1 = (y1 >> 2) - yo1 + py;
-    if (__ballot(f0 != 0)) fill_tiles<PW, LPP>(win0, t, bx0, by0, l);  // integer positions read only the window
+    if (__ballot(f0 != 0)) fill_tiles<Tiles<PW, PH>, LPP>(win0, t, bx0, by0, l);  // integer positions read only the window
     {
         const int e0 = kBiFrac[f0][0], e1 = kBiFrac[f0][1];
 #pragma unroll 2
-        for (int i = l; i < (PW / 4) * PW; i += LPP) {  // 4 pixels per step
+        for (int i = l; i < (PW / 4) * PH; i += LPP) {  // 4 pixels per step
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            reinterpret_cast<lds_u32*>(pred0)[i] = bipred_sample4<PW>(win0, t, e0, e1, bx0 + x, by0 + y, bx0, by0);
+            reinterpret_cast<lds_u32*>(pred0)[i] = bipred_sample4(win0, t, e0, e1, bx0 + x, by0 + y, bx0, by0);
         }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (__ballot(f1 != 0)) fill_tiles<PW, LPP>(win1, t, bx1, by1, l);
+    if (__ballot(f1 != 0)) fill_tiles<Tiles<PW, PH>, LPP>(win1, t, bx1, by1, l);
     uint32_t sad = 0;
     {
         const int e0 = kBiFrac[f1][0], e1 = kBiFrac[f1][1];
 #pragma unroll 2
-        for (int i = l; i < (PW / 4) * PW; i += LPP) {
+        for (int i = l; i < (PW / 4) * PH; i += LPP) {
             const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            const uint32_t p1 = bipred_sample4<PW>(win1, t, e0, e1, bx1 + x, by1 + y, bx1, by1);
+            const uint32_t p1 = bipred_sample4(win1, t, e0, e1, bx1 + x, by1 + y, bx1, by1);
             const uint32_t avg = avg_u8x4(reinterpret_cast<const lds_u32*>(pred0)[i], p1);
             sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x), avg, sad);
         }
@@ -496,7 +494,10 @@ __device__ uint32_t bipred_pu(const lds_u8* src, const Win& win0, const Win& win
     return gsum<LPP>(sad);
 }
 
-__device__ void stage_window(lds_u8* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid)
+
+// stage the integer window of one list: search position (0,0) at [kMargin][kMargin]
+__device__ void stage_window(lds_u8* wbuf, int pitch, int wrows, const uint8_t* ref_plane, int ref_off, uint32_t ref_stride, int tid,
+                             int nthreads = 256)
 {
     const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
@@ -505,11 +506,119 @@ __device__ void stage_window(lds_u8* wbuf, int pitch, int wrows, const uint8_t* 
     const int ndw = pitch >> 2, rstride4 = ref_stride >> 2;
     const int total = wrows * ndw;
     const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;
-    for (int i = tid; i < total; i += 256) {
+    for (int i = tid; i < total; i += nthreads) {
         const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
         const uint32_t* p = base4 + (size_t)r * rstride4 + c;
         reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
     }
+}
+
+// ---- the 124 rectangular PUs of the 209-PU mode -------------------------------------------------------------------------
+// me_results / the packing loop index PUs in raster order within each shape class; the ME buffers hold each class in the order
+// the full-pel stage fills it (z-order of the constituent squares; tab32x16 .. tab8x32, Codec/EbMotionEstimation.h:123-171).
+// Table by raster PU index: position in the SB and ME-buffer index, derived from that buffer order.
+struct PuTab {
+    uint8_t me[209], px[209], py[209];
+};
+constexpr int z4(int col, int row) { return ((row >> 1) * 2 + (col >> 1)) * 4 + (row & 1) * 2 + (col & 1); }
+constexpr PuTab make_pu_tab()
+{
+    PuTab t{};
+    // class: base, count, w, h, columns
+    const int cls[14][5] = {{0, 1, 64, 64, 1},   {1, 4, 32, 32, 2},   {5, 16, 16, 16, 4},  {21, 64, 8, 8, 8},   {85, 2, 64, 32, 1},
+                            {87, 8, 32, 16, 2},  {95, 32, 16, 8, 4},  {127, 2, 32, 64, 2}, {129, 8, 16, 32, 4}, {137, 32, 8, 16, 8},
+                            {169, 16, 32, 8, 2}, {185, 16, 8, 32, 8}, {201, 4, 64, 16, 1}, {205, 4, 16, 64, 4}};
+    for (int c = 0; c < 14; c++)
+        for (int p = 0; p < cls[c][1]; p++) {
+            const int base = cls[c][0], col = p % cls[c][4], row = p / cls[c][4];
+            int i = p;  // 64x64, 32x32, 64x32, 32x64, 16x32, 8x32, 64x16, 16x64: buffer order = raster
+            if (base == 5) i = z4(col, row);                                              // 16x16: z-order
+            if (base == 21) i = 4 * z4(col >> 1, row >> 1) + (row & 1) * 2 + (col & 1);   // 8x8: raster inside its 16x16
+            if (base == 87) i = 2 * ((row >> 1) * 2 + col) + (row & 1);                   // 32x16: (quadrant, upper / lower)
+            if (base == 95) i = 2 * z4(col, row >> 1) + (row & 1);                        // 16x8: (16x16 z, upper / lower)
+            if (base == 137) i = 2 * z4(col >> 1, row) + (col & 1);                       // 8x16: (16x16 z, left / right)
+            if (base == 169) i = 4 * ((row >> 2) * 2 + col) + (row & 3);                  // 32x8: (quadrant, row of 8)
+            t.me[base + p] = (uint8_t)(base + i);
+            t.px[base + p] = (uint8_t)(col * cls[c][2]);
+            t.py[base + p] = (uint8_t)(row * cls[c][3]);
+        }
+    return t;
+}
+__device__ constexpr PuTab kPu = make_pu_tab();
+
+// Five wave roles, two shape classes each (a horizontal class and its transpose: equal pixel area per role):
+//   0: 64x32 | 32x64   1: 64x16 | 16x64   2: 32x16 | 16x32   3: 32x8 | 8x32   4: 16x8 | 8x16
+// with 64 / 64 / 32 / 16 / 8 lanes per PU.  Tile memory per role = the larger of its two classes times the PUs per pass.
+constexpr int kNsqRoles = 5;
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int kNsqTile[kNsqRoles] = {cmax(Tiles<64, 32>::bytes, Tiles<32, 64>::bytes), cmax(Tiles<64, 16>::bytes, Tiles<16, 64>::bytes),
+                                     2 * cmax(Tiles<32, 16>::bytes, Tiles<16, 32>::bytes), 4 * cmax(Tiles<32, 8>::bytes, Tiles<8, 32>::bytes),
+                                     8 * cmax(Tiles<16, 8>::bytes, Tiles<8, 16>::bytes)};
+__device__ constexpr int kNsqTileOff[kNsqRoles + 1] = {0, kNsqTile[0], kNsqTile[0] + kNsqTile[1], kNsqTile[0] + kNsqTile[1] + kNsqTile[2],
+                                            kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3],
+                                            (kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3] + kNsqTile[4] + 15) & ~15};
+__device__ constexpr int kNsqPredOff[kNsqRoles + 1] = {0, 2048, 3072, 4096, 5120, 6144};  // list-0 predictions: PUs per pass x PW x PH bytes
+
+// sub-pel refinement of the `count` PUs of one shape class starting at raster PU index `base`, 64 / LPP of them per pass
+template <int PW, int PH, int LPP>
+__device__ void refine_class(const lds_u8* src, const Win& win, lds_u8* tiles, int xo, int yo, int lane, uint32_t* sad_io, uint32_t* mv_io,
+                             int base, int count)
+{
+    constexpr int G = 64 / LPP;
+    const int g = lane / LPP, l = lane % LPP;
+    Tiles<PW, PH> t = Tiles<PW, PH>::at(tiles + g * Tiles<PW, PH>::bytes);
+#pragma unroll 1
+    for (int p = g; p < count; p += G) {
+        const int pu = base + p;
+        refine_pu<PW, PH, LPP>(src, win, t, kPu.px[pu], kPu.py[pu], xo, yo, l, sad_io, mv_io, kPu.me[pu]);
+    }
+}
+
+// bi-prediction SADs of one shape class into bisad[] (ME-buffer index)
+template <int PW, int PH, int LPP>
+__device__ void bipred_class(const lds_u8* src, const Win& win0, const Win& win1, lds_u8* tiles, lds_u8* pred, const uint32_t* m0, int xo0,
+                             int yo0, const uint32_t* m1, int xo1, int yo1, int lane, uint32_t* bisad, int base, int count)
+{
+    constexpr int G = 64 / LPP;
+    const int g = lane / LPP, l = lane % LPP;
+    Tiles<PW, PH> t = Tiles<PW, PH>::at(tiles + g * Tiles<PW, PH>::bytes);
+#pragma unroll 1
+    for (int p = g; p < count; p += G) {
+        const int pu = base + p, n = kPu.me[pu];
+        const uint32_t v = bipred_pu<PW, PH, LPP>(src, win0, win1, t, pred + g * PW * PH, kPu.px[pu], kPu.py[pu], m0[n], xo0, yo0, m1[n],
+                                                  xo1, yo1, l);
+        if (l == 0) bisad[n] = v;
+    }
+}
+
+// one me_results entry: a / b = list-0 / list-1 SAD, c = bi-pred SAD, total = number of candidates (1, 2 or 3)
+__device__ __forceinline__ svthip_me_cu_result pack_result(uint32_t a, uint32_t mv0, uint32_t b, uint32_t mv1, uint32_t c, int n_lists, int total)
+{
+    svthip_me_cu_result o;
+    o.xMvL0 = (int16_t)(mv0 & 0xffffu);
+    o.yMvL0 = (int16_t)(mv0 >> 16);
+    o.xMvL1 = n_lists == 2 ? (int16_t)(mv1 & 0xffffu) : 0;
+    o.yMvL1 = n_lists == 2 ? (int16_t)(mv1 >> 16) : 0;
+    for (int k = 0; k < 3; k++) { o.distortion[k] = 0; o.direction[k] = 0; }
+    if (total == 3) {
+        int o0, o1, o2;  // Sort3Elements (:5434-5463)
+        if (a <= b && a <= c) { o0 = 0; if (b <= c) { o1 = 1; o2 = 2; } else { o1 = 2; o2 = 1; } }
+        else if (b <= a && b <= c) { o0 = 1; if (a <= c) { o1 = 0; o2 = 2; } else { o1 = 2; o2 = 0; } }
+        else if (a <= b) { o0 = 2; o1 = 0; o2 = 1; }
+        else { o0 = 2; o1 = 1; o2 = 0; }
+        const uint32_t v[3] = {a, b, c};
+        o.distortion[0] = v[o0]; o.direction[0] = (uint8_t)o0;
+        o.distortion[1] = v[o1]; o.direction[1] = (uint8_t)o1;
+        o.distortion[2] = v[o2]; o.direction[2] = (uint8_t)o2;
+    } else if (total == 2) {
+        if (a <= b) { o.distortion[0] = a; o.direction[0] = 0; o.distortion[1] = b; o.direction[1] = 1; }
+        else { o.distortion[0] = b; o.direction[0] = 1; o.distortion[1] = a; o.direction[1] = 0; }
+    } else {
+        o.distortion[0] = a;
+        o.direction[0] = 0;
+    }
+    o.totalMeCandidateIndex = (uint8_t)total;
+    return o;
 }
 
 }  // namespace
@@ -521,7 +630,8 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
                                                           const int32_t* __restrict__ desc1, const uint32_t* __restrict__ sad0,
                                                           const uint32_t* __restrict__ mv0, const uint32_t* __restrict__ sad1,
                                                           const uint32_t* __restrict__ mv1, int n_lists, int bipred_8x8,
-                                                          int win_bytes, svthip_me_cu_result* __restrict__ out)
+                                                          int win_bytes, int pu_stride, uint32_t* __restrict__ bisad_out,
+                                                          svthip_me_cu_result* __restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t bisad[85];  // indexed by ME-buffer PU index
@@ -531,10 +641,10 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
     // workgroup index to even out the four SIMDs of a CU.
     const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);
     const size_t sb = blockIdx.x;
-    const uint32_t* s0 = sad0 + 85 * sb;
-    const uint32_t* m0 = mv0 + 85 * sb;
-    const uint32_t* s1 = n_lists == 2 ? sad1 + 85 * sb : s0;
-    const uint32_t* m1 = n_lists == 2 ? mv1 + 85 * sb : m0;
+    const uint32_t* s0 = sad0 + pu_stride * sb;
+    const uint32_t* m0 = mv0 + pu_stride * sb;
+    const uint32_t* s1 = n_lists == 2 ? sad1 + pu_stride * sb : s0;
+    const uint32_t* m1 = n_lists == 2 ? mv1 + pu_stride * sb : m0;
 
     if (n_lists == 2) {
         const int32_t* d0 = desc0 + 6 * sb;
@@ -559,13 +669,13 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
         const int xo0 = d0[2], yo0 = d0[3], xo1 = d1[2], yo1 = d1[3];
         if (wave == 0) {
             Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-            const uint32_t v = bipred_pu<64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
+            const uint32_t v = bipred_pu<64, 64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
             if (lane == 0) bisad[0] = v;
         } else if (wave == 1) {
             lds_u8* b = tile_base + t64;
             Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
             for (int p = 0; p < 4; p++) {
-                const uint32_t v = bipred_pu<32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p],
+                const uint32_t v = bipred_pu<32, 32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p],
                                                      xo0, yo0, m1[1 + p], xo1, yo1, lane);
                 if (lane == 0) bisad[1 + p] = v;
             }
@@ -576,7 +686,7 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             for (int pass = 0; pass < 4; pass++) {
                 const int p = pass * 4 + g;
                 const int n = 5 + kTab16[p];
-                const uint32_t v = bipred_pu<16, 16>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + g * 256, (p & 3) << 4, (p >> 2) << 4,
+                const uint32_t v = bipred_pu<16, 16, 16>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + g * 256, (p & 3) << 4, (p >> 2) << 4,
                                                      m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 15);
                 if ((lane & 15) == 0) bisad[n] = v;
             }
@@ -587,47 +697,143 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             for (int pass = 0; pass < 8; pass++) {
                 const int p = pass * 8 + g;
                 const int n = 21 + kTab8[p];
-                const uint32_t v = bipred_pu<8, 8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + kGroups16 * 256 + g * 64, (p & 7) << 3,
+                const uint32_t v = bipred_pu<8, 8, 8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + kGroups16 * 256 + g * 64, (p & 7) << 3,
                                                    (p >> 3) << 3, m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 7);
                 if ((lane & 7) == 0) bisad[n] = v;
             }
         }
         __syncthreads();
     }
+    if (bisad_out) {  // 209-PU mode: the squares' bi-pred SADs go to bipred_nsq_pack_kernel, which packs all 209 PUs
+        if (tid < 85) bisad_out[85 * sb + tid] = bisad[tid];
+        return;
+    }
 
     if (tid < 85) {
         // me_results[sb][pu] in raster PU order; n = ME-buffer index (:6980-7015)
         const int pu = tid;
         const int n = pu > 20 ? kTab8[pu - 21] + 21 : (pu > 4 ? kTab16[pu - 5] + 5 : pu);
-        svthip_me_cu_result o;
-        o.xMvL0 = (int16_t)(m0[n] & 0xffffu);
-        o.yMvL0 = (int16_t)(m0[n] >> 16);
-        o.xMvL1 = n_lists == 2 ? (int16_t)(m1[n] & 0xffffu) : 0;
-        o.yMvL1 = n_lists == 2 ? (int16_t)(m1[n] >> 16) : 0;
-        for (int k = 0; k < 3; k++) { o.distortion[k] = 0; o.direction[k] = 0; }
-        const uint32_t a = s0[n], b = n_lists == 2 ? s1[n] : 0u;
         int total = n_lists;
         if (n_lists == 2 && (bipred_8x8 || pu < 21)) total = 3;
-        if (total == 3) {
-            const uint32_t c = bisad[n];
-            int o0, o1, o2;  // Sort3Elements (:5434-5463)
-            if (a <= b && a <= c) { o0 = 0; if (b <= c) { o1 = 1; o2 = 2; } else { o1 = 2; o2 = 1; } }
-            else if (b <= a && b <= c) { o0 = 1; if (a <= c) { o1 = 0; o2 = 2; } else { o1 = 2; o2 = 0; } }
-            else if (a <= b) { o0 = 2; o1 = 0; o2 = 1; }
-            else { o0 = 2; o1 = 1; o2 = 0; }
-            const uint32_t v[3] = {a, b, c};
-            o.distortion[0] = v[o0]; o.direction[0] = (uint8_t)o0;
-            o.distortion[1] = v[o1]; o.direction[1] = (uint8_t)o1;
-            o.distortion[2] = v[o2]; o.direction[2] = (uint8_t)o2;
-        } else if (total == 2) {
-            if (a <= b) { o.distortion[0] = a; o.direction[0] = 0; o.distortion[1] = b; o.direction[1] = 1; }
-            else { o.distortion[0] = b; o.direction[0] = 1; o.distortion[1] = a; o.direction[1] = 0; }
-        } else {
-            o.distortion[0] = a;
-            o.direction[0] = 0;
+        out[85 * sb + pu] = pack_result(s0[n], m0[n], n_lists == 2 ? s1[n] : 0u, m1[n], total == 3 ? bisad[n] : 0u, n_lists, total);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 209-PU mode: sub-pel refinement of the 124 rectangular PUs (HalfPelSearch_LCU :2418-2786, QuarterPelSearch_LCU
+// :3580-4114).  io arrays are [n_sb][209] in ME-buffer order; the squares (entries 0..84) are refined by subpel85_kernel.
+// One 320-thread workgroup per (SB, list), wave role = (wave + SB) mod 5.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(320) subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                                         const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
+                                                         const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
+                                                         uint32_t* __restrict__ io_mv)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int role = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) % kNsqRoles);
+    const int32_t* d = desc + 6 * blockIdx.x;
+    const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
+    // LDS: [src 64x64][tiles of the five roles][window]
+    lds_u8* src_lds = (lds_u8*)smem;
+    lds_u8* tile_base = src_lds + 4096;
+    lds_u8* wbuf = tile_base + kNsqTileOff[kNsqRoles];
+    const int pitch = (sw + 63 + 2 * kMargin + 3) & ~3;
+    for (int i = tid; i < 64 * 16; i += 320) {
+        const int r = i >> 4, c = i & 15;
+        reinterpret_cast<lds_u32*>(src_lds)[i] = *reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)r * src_stride + 4 * c);
+    }
+    stage_window(wbuf, pitch, sh + 63 + 2 * kMargin, ref_plane, ref_off, ref_stride, tid, 320);
+    __syncthreads();
+    Win win{wbuf, pitch};
+    uint32_t* sad_io = io_sad + (size_t)209 * blockIdx.x;
+    uint32_t* mv_io = io_mv + (size_t)209 * blockIdx.x;
+    lds_u8* tiles = tile_base + kNsqTileOff[role];
+    if (role == 0) {
+        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2);
+        refine_class<32, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 127, 2);
+    } else if (role == 1) {
+        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4);
+        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4);
+    } else if (role == 2) {
+        refine_class<32, 16, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 87, 8);
+        refine_class<16, 32, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 129, 8);
+    } else if (role == 3) {
+        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16);
+        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16);
+    } else {
+        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32);
+        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32);
+    }
+}
+
+// 209-PU mode: bi-prediction SADs of the rectangular PUs, then packing of all 209 PUs (:6973-7146; in this mode every PU
+// gets a bi-pred candidate whatever cu8x8_mode is, :7028).  bisad_sq = the squares' bi-pred SADs from bipred_pack_kernel,
+// [n_sb][85] in ME-buffer order.  sad / mv arrays are [n_sb][209]; out is [n_sb][209] in raster PU order.
+__global__ void __launch_bounds__(320) bipred_nsq_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                                              const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride,
+                                                              const int32_t* __restrict__ desc0,
+                                                              const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride,
+                                                              const int32_t* __restrict__ desc1, const uint32_t* __restrict__ sad0,
+                                                              const uint32_t* __restrict__ mv0, const uint32_t* __restrict__ sad1,
+                                                              const uint32_t* __restrict__ mv1, int n_lists, int win_bytes,
+                                                              const uint32_t* __restrict__ bisad_sq,
+                                                              svthip_me_cu_result* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t bisad[209];  // indexed by ME-buffer PU index
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int role = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) % kNsqRoles);
+    const size_t sb = blockIdx.x;
+    const uint32_t* s0 = sad0 + 209 * sb;
+    const uint32_t* m0 = mv0 + 209 * sb;
+    const uint32_t* s1 = n_lists == 2 ? sad1 + 209 * sb : s0;
+    const uint32_t* m1 = n_lists == 2 ? mv1 + 209 * sb : m0;
+
+    if (n_lists == 2) {
+        const int32_t* d0 = desc0 + 6 * sb;
+        const int32_t* d1 = desc1 + 6 * sb;
+        // LDS: [src 4096][pred0 of the five roles][tiles of the five roles][window 0][window 1]
+        lds_u8* src_lds = (lds_u8*)smem;
+        lds_u8* pred_base = src_lds + 4096;
+        lds_u8* tile_base = pred_base + kNsqPredOff[kNsqRoles];
+        lds_u8* w0buf = tile_base + kNsqTileOff[kNsqRoles];
+        lds_u8* w1buf = w0buf + win_bytes;
+        const int pitch0 = (d0[4] + 63 + 2 * kMargin + 3) & ~3, pitch1 = (d1[4] + 63 + 2 * kMargin + 3) & ~3;
+        for (int i = tid; i < 64 * 16; i += 320) {
+            const int r = i >> 4, c = i & 15;
+            reinterpret_cast<lds_u32*>(src_lds)[i] = *reinterpret_cast<const uint32_t*>(src_plane + d0[0] + (size_t)r * src_stride + 4 * c);
         }
-        o.totalMeCandidateIndex = (uint8_t)total;
-        out[85 * sb + pu] = o;
+        stage_window(w0buf, pitch0, d0[5] + 63 + 2 * kMargin, ref0_plane, d0[1], ref0_stride, tid, 320);
+        stage_window(w1buf, pitch1, d1[5] + 63 + 2 * kMargin, ref1_plane, d1[1], ref1_stride, tid, 320);
+        if (tid < 85) bisad[tid] = bisad_sq[85 * sb + tid];
+        __syncthreads();
+        Win win0{w0buf, pitch0}, win1{w1buf, pitch1};
+        const int xo0 = d0[2], yo0 = d0[3], xo1 = d1[2], yo1 = d1[3];
+        lds_u8* tiles = tile_base + kNsqTileOff[role];
+        lds_u8* pred = pred_base + kNsqPredOff[role];
+        if (role == 0) {
+            bipred_class<64, 32, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 85, 2);
+            bipred_class<32, 64, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 127, 2);
+        } else if (role == 1) {
+            bipred_class<64, 16, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 201, 4);
+            bipred_class<16, 64, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 205, 4);
+        } else if (role == 2) {
+            bipred_class<32, 16, 32>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 87, 8);
+            bipred_class<16, 32, 32>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 129, 8);
+        } else if (role == 3) {
+            bipred_class<32, 8, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 169, 16);
+            bipred_class<8, 32, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 185, 16);
+        } else {
+            bipred_class<16, 8, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 95, 32);
+            bipred_class<8, 16, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 137, 32);
+        }
+        __syncthreads();
+    }
+
+    if (tid < 209) {
+        const int pu = tid, n = kPu.me[pu];  // me_results[sb][pu] in raster PU order; n = ME-buffer index (:6980-7015)
+        out[209 * sb + pu] = pack_result(s0[n], m0[n], n_lists == 2 ? s1[n] : 0u, m1[n], n_lists == 2 ? bisad[n] : 0u, n_lists, n_lists == 2 ? 3 : 1);
     }
 }
 
@@ -640,6 +846,13 @@ size_t subpel_window_bytes(uint32_t max_sw, uint32_t max_sh)
 size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
     return 4096 + kPredBytes + kTileBytes + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
+}
+
+size_t subpel_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh) { return 4096 + kNsqTileOff[kNsqRoles] + subpel_window_bytes(max_sw, max_sh) + 16; }
+
+size_t bipred_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh)
+{
+    return 4096 + kNsqPredOff[kNsqRoles] + kNsqTileOff[kNsqRoles] + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
 }
 
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh)

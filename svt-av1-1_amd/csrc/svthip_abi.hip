@@ -35,8 +35,8 @@ struct svthip_ctx {
     int device;
     hipStream_t stream;
     // grow-only device scratch for the host-pointer entry points
-    void* scratch[6];
-    size_t scratch_bytes[6];
+    void* scratch[8];
+    size_t scratch_bytes[8];
     int max_dyn_lds_set;
     int max_dyn_lds_search;
     int max_dyn_lds_209;
@@ -112,7 +112,7 @@ void svthip_destroy(svthip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -138,10 +138,10 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
                           max_search_area_height, d_best_sad, d_best_mv, s);
 }
 
-int32_t svthip_me_subpel_refine_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
-                                    uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb,
-                                    uint32_t max_search_area_width, uint32_t max_search_area_height,
-                                    int32_t disable_8x8_refinement, uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
+static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                     uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_search_area_width,
+                                     uint32_t max_search_area_height, int32_t disable_8x8_refinement, int n_pu, uint32_t* d_best_sad,
+                                     uint32_t* d_best_mv, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (n_sb == 0) return SVTHIP_OK;
@@ -152,12 +152,95 @@ int32_t svthip_me_subpel_refine_dev(svthip_ctx* ctx, const uint8_t* d_src_plane,
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     const size_t lds = svthip::subpel_lds_bytes(max_search_area_width, max_search_area_height);
-    if (lds > 160 * 1024) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
+    const size_t lds_nsq = svthip::subpel_nsq_lds_bytes(max_search_area_width, max_search_area_height);
+    if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel85_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, d_best_sad, d_best_mv);
+                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv);
+    HIP_TRY(hipGetLastError());
+    if (n_pu == 209) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nsq));
+        hipLaunchKernelGGL(svthip::subpel_nsq_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
+                           reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv);
+        HIP_TRY(hipGetLastError());
+    }
+    return SVTHIP_OK;
+}
+
+int32_t svthip_me_subpel_refine_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                    uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb,
+                                    uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                    int32_t disable_8x8_refinement, uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
+{
+    return subpel_refine_common(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
+                                max_search_area_height, disable_8x8_refinement, 85, d_best_sad, d_best_mv, stream);
+}
+
+int32_t svthip_me_subpel_refine209_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                       uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb,
+                                       uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                       int32_t disable_8x8_refinement, uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
+{
+    return subpel_refine_common(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
+                                max_search_area_height, disable_8x8_refinement, 209, d_best_sad, d_best_mv, stream);
+}
+
+static int32_t bipred_pack_common(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref0_plane,
+                                  uint32_t ref0_stride, const svthip_fullpel_desc* d_desc0, const uint8_t* d_ref1_plane,
+                                  uint32_t ref1_stride, const svthip_fullpel_desc* d_desc1, uint32_t n_sb,
+                                  uint32_t max_search_area_width, uint32_t max_search_area_height, const uint32_t* d_sad0,
+                                  const uint32_t* d_mv0, const uint32_t* d_sad1, const uint32_t* d_mv1, uint32_t n_lists,
+                                  int32_t bipred_8x8, int n_pu, svthip_me_cu_result* d_out, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_sb == 0) return SVTHIP_OK;
+    if (n_lists < 1 || n_lists > 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_lists must be 1 or 2%s", "");
+    if (!d_sad0 || !d_mv0 || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    size_t lds = 0, lds_nsq = 0;
+    int win_bytes = 0;
+    if (n_lists == 2) {
+        if (!d_src_plane || !d_ref0_plane || !d_ref1_plane || !d_desc0 || !d_desc1 || !d_sad1 || !d_mv1)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+        if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127%s", "");
+        if ((src_stride & 3u) || (ref0_stride & 3u) || (ref1_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
+        lds = svthip::bipred_lds_bytes(max_search_area_width, max_search_area_height);
+        lds_nsq = svthip::bipred_nsq_lds_bytes(max_search_area_width, max_search_area_height);
+        win_bytes = (int)svthip::subpel_window_bytes(max_search_area_width, max_search_area_height);
+        if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS windows%s", "");
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_pack_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (n_pu == 85) {
+        hipLaunchKernelGGL(svthip::bipred_pack_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
+                           reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
+                           d_sad0, d_mv0, d_sad1, d_mv1, (int)n_lists, (int)bipred_8x8, win_bytes, 85, (uint32_t*)nullptr, d_out);
+        HIP_TRY(hipGetLastError());
+        return SVTHIP_OK;
+    }
+    // 209-PU mode: the squares' bi-pred SADs go through scratch slot 6 ([n_sb][85]) to the kernel that packs all 209 PUs
+    uint32_t* bisad_sq = nullptr;
+    if (n_lists == 2) {
+        int32_t rc;
+        if ((rc = ensure_scratch(ctx, 6, sizeof(uint32_t) * 85 * (size_t)n_sb))) return rc;
+        bisad_sq = static_cast<uint32_t*>(ctx->scratch[6]);
+        hipLaunchKernelGGL(svthip::bipred_pack_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
+                           reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
+                           d_sad0, d_mv0, d_sad1, d_mv1, 2, 1, win_bytes, 209, bisad_sq, (svthip_me_cu_result*)nullptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nsq));
+    }
+    hipLaunchKernelGGL(svthip::bipred_nsq_pack_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
+                       reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
+                       d_sad0, d_mv0, d_sad1, d_mv1, (int)n_lists, win_bytes, (const uint32_t*)bisad_sq, d_out);
     HIP_TRY(hipGetLastError());
     return SVTHIP_OK;
 }
@@ -169,31 +252,20 @@ int32_t svthip_me_bipred_pack_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, u
                                   const uint32_t* d_mv0, const uint32_t* d_sad1, const uint32_t* d_mv1, uint32_t n_lists,
                                   int32_t bipred_8x8, svthip_me_cu_result* d_out, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
-    if (n_sb == 0) return SVTHIP_OK;
-    if (n_lists < 1 || n_lists > 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_lists must be 1 or 2%s", "");
-    if (!d_sad0 || !d_mv0 || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
-    size_t lds = 0;
-    int win_bytes = 0;
-    if (n_lists == 2) {
-        if (!d_src_plane || !d_ref0_plane || !d_ref1_plane || !d_desc0 || !d_desc1 || !d_sad1 || !d_mv1)
-            return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
-        if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
-            return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127%s", "");
-        if ((src_stride & 3u) || (ref0_stride & 3u) || (ref1_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
-            return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
-        lds = svthip::bipred_lds_bytes(max_search_area_width, max_search_area_height);
-        win_bytes = (int)svthip::subpel_window_bytes(max_search_area_width, max_search_area_height);
-        if (lds > 160 * 1024) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS windows%s", "");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_pack_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(svthip::bipred_pack_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
-                       reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
-                       d_sad0, d_mv0, d_sad1, d_mv1, (int)n_lists, (int)bipred_8x8, win_bytes, d_out);
-    HIP_TRY(hipGetLastError());
-    return SVTHIP_OK;
+    return bipred_pack_common(ctx, d_src_plane, src_stride, d_ref0_plane, ref0_stride, d_desc0, d_ref1_plane, ref1_stride, d_desc1, n_sb,
+                              max_search_area_width, max_search_area_height, d_sad0, d_mv0, d_sad1, d_mv1, n_lists, bipred_8x8, 85, d_out,
+                              stream);
+}
+
+int32_t svthip_me_bipred_pack209_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref0_plane,
+                                     uint32_t ref0_stride, const svthip_fullpel_desc* d_desc0, const uint8_t* d_ref1_plane,
+                                     uint32_t ref1_stride, const svthip_fullpel_desc* d_desc1, uint32_t n_sb,
+                                     uint32_t max_search_area_width, uint32_t max_search_area_height, const uint32_t* d_sad0,
+                                     const uint32_t* d_mv0, const uint32_t* d_sad1, const uint32_t* d_mv1, uint32_t n_lists,
+                                     svthip_me_cu_result* d_out, void* stream)
+{
+    return bipred_pack_common(ctx, d_src_plane, src_stride, d_ref0_plane, ref0_stride, d_desc0, d_ref1_plane, ref1_stride, d_desc1, n_sb,
+                              max_search_area_width, max_search_area_height, d_sad0, d_mv0, d_sad1, d_mv1, n_lists, 1, 209, d_out, stream);
 }
 
 int32_t svthip_quantize_b_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff, const svthip_quant_desc* d_desc, uint32_t n_tu,
@@ -416,11 +488,11 @@ int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, 
                                                  d_desc, d_center, d_hme_state, stream);
 }
 
-int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                         const svthip_pa_picture* ref0, const svthip_pa_picture* ref1, uint32_t n_jobs,
-                                         const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
-                                         const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
-                                         uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                            const svthip_pa_picture* ref0, const svthip_pa_picture* ref1, uint32_t n_jobs,
+                                            const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                            const svthip_sb_origin* d_sb, uint32_t n_sb, uint32_t n_pu, svthip_me_cu_result* d_out,
+                                            uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
@@ -432,8 +504,8 @@ int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool,
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n_lists = ref1 ? 2u : 1u;
     const size_t n = (size_t)n_jobs * n_sb;
-    // scratch: slot 5 holds  desc[2][n] | sad[2][n][85] | mv[2][n][85] | hme_state[n][25]
-    const size_t desc_b = sizeof(svthip_fullpel_desc) * n, arr_b = sizeof(uint32_t) * 85 * n;
+    // scratch: slot 5 holds  desc[2][n] | sad[2][n][n_pu] | mv[2][n][n_pu] | hme_state[n][25]
+    const size_t desc_b = sizeof(svthip_fullpel_desc) * n, arr_b = sizeof(uint32_t) * n_pu * n;
     const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * n) + 15) & ~(size_t)15;
     int32_t rc;
     if ((rc = ensure_scratch(ctx, 5, 2 * desc_b + 4 * arr_b + state_b + 64))) return rc;
@@ -443,8 +515,8 @@ int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool,
     uint32_t* mv[2] = {reinterpret_cast<uint32_t*>(base + 2 * desc_b + 2 * arr_b), reinterpret_cast<uint32_t*>(base + 2 * desc_b + 3 * arr_b)};
     int16_t* state = reinterpret_cast<int16_t*>(base + 2 * desc_b + 4 * arr_b);
     if (d_list_sad && d_list_mv) {  // caller wants the per-list arrays: write them in place
-        sad[0] = d_list_sad; sad[1] = d_list_sad + 85 * n;
-        mv[0] = d_list_mv; mv[1] = d_list_mv + 85 * n;
+        sad[0] = d_list_sad; sad[1] = d_list_sad + n_pu * n;
+        mv[0] = d_list_mv; mv[1] = d_list_mv + n_pu * n;
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const uint32_t sw = params->search_area_width < 127 ? params->search_area_width : 127;
@@ -452,21 +524,43 @@ int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool,
     const svthip_pa_picture* refs[2] = {ref0, ref1};
     // seven launches whatever the number of pictures: per list search centres -> full-pel -> sub-pel, then bi-prediction + packing
     for (uint32_t l = 0; l < n_lists; l++) {
-        if ((rc = svthip_me_hme_search_center_batch_dev(ctx, d_pool, cur, refs[l], n_jobs, params, l, d_sb, n_sb, l ? mv[0] : nullptr, 85,
+        if ((rc = svthip_me_hme_search_center_batch_dev(ctx, d_pool, cur, refs[l], n_jobs, params, l, d_sb, n_sb, l ? mv[0] : nullptr, n_pu,
                                                         desc[l], nullptr, state, s)))
             return rc;
-        if ((rc = launch_fullpel(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh, sad[l], mv[l], s)))
-            return rc;
+        rc = n_pu == 209 ? svthip_me_fullpel_search209_dev(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh,
+                                                           sad[l], mv[l], s)
+                         : launch_fullpel(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh, sad[l], mv[l], s);
+        if (rc) return rc;
         if (use_subpel_flag &&
-            (rc = svthip_me_subpel_refine_dev(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh,
-                                              cu8x8_mode == 1, sad[l], mv[l], s)))
+            (rc = subpel_refine_common(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh,
+                                       cu8x8_mode == 1, (int)n_pu, sad[l], mv[l], s)))
             return rc;
     }
-    return svthip_me_bipred_pack_dev(ctx, d_pool, cur->full_stride, d_pool, ref0->full_stride, desc[0], n_lists == 2 ? d_pool : nullptr,
-                                     n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, (uint32_t)n, sw, sh, sad[0],
-                                     mv[0], n_lists == 2 ? sad[1] : nullptr, n_lists == 2 ? mv[1] : nullptr, n_lists, cu8x8_mode == 0,
-                                     d_out, s);
+    return bipred_pack_common(ctx, d_pool, cur->full_stride, d_pool, ref0->full_stride, desc[0], n_lists == 2 ? d_pool : nullptr,
+                              n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, (uint32_t)n, sw, sh, sad[0], mv[0],
+                              n_lists == 2 ? sad[1] : nullptr, n_lists == 2 ? mv[1] : nullptr, n_lists, cu8x8_mode == 0, (int)n_pu, d_out, s);
 }
+
+int32_t svthip_motion_estimate_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                         const svthip_pa_picture* ref0, const svthip_pa_picture* ref1, uint32_t n_jobs,
+                                         const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                         const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
+                                         uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+{
+    return motion_estimate_batch_common(ctx, d_pool, cur, ref0, ref1, n_jobs, params, use_subpel_flag, cu8x8_mode, d_sb, n_sb, 85, d_out,
+                                        d_list_sad, d_list_mv, stream);
+}
+
+int32_t svthip_motion_estimate209_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                            const svthip_pa_picture* ref0, const svthip_pa_picture* ref1, uint32_t n_jobs,
+                                            const svthip_me_params* params, int32_t use_subpel_flag, int32_t cu8x8_mode,
+                                            const svthip_sb_origin* d_sb, uint32_t n_sb, svthip_me_cu_result* d_out,
+                                            uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
+{
+    return motion_estimate_batch_common(ctx, d_pool, cur, ref0, ref1, n_jobs, params, use_subpel_flag, cu8x8_mode, d_sb, n_sb, 209, d_out,
+                                        d_list_sad, d_list_mv, stream);
+}
+
 
 int32_t svthip_motion_estimate_picture_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
                                            const svthip_pa_picture* ref0, const svthip_pa_picture* ref1,

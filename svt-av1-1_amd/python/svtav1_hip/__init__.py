@@ -93,6 +93,14 @@ def lib() -> C.CDLL:
     L.svthip_me_bipred_pack_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.svthip_me_subpel_refine209_dev.restype = C.c_int32
+    L.svthip_me_subpel_refine209_dev.argtypes = L.svthip_me_subpel_refine_dev.argtypes
+    L.svthip_me_bipred_pack209_dev.restype = C.c_int32
+    L.svthip_me_bipred_pack209_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                               C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.svthip_motion_estimate209_batch_dev.restype = C.c_int32
+    L.svthip_motion_estimate209_batch_dev.argtypes = L.svthip_motion_estimate_batch_dev.argtypes
     L.svthip_quantize_b_batch_dev.restype = C.c_int32
     L.svthip_quantize_b_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
@@ -256,6 +264,35 @@ def _bipred_pack_dev(self, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_re
 
 
 Context.bipred_pack_dev = _bipred_pack_dev
+
+
+def _subpel_refine209_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv, disable_8x8=False,
+                          stream=None):
+    """Sub-pel refinement of all 209 PUs; d_sad / d_mv: [n_sb][209] uint32 device arrays (ME-buffer order), in place."""
+    _check(lib().svthip_me_subpel_refine209_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh,
+                                                int(disable_8x8), d_sad, d_mv, stream))
+
+
+def _bipred_pack209_dev(self, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_ref1, ref1_stride, d_desc1, n_sb, max_sw, max_sh,
+                        d_sad0, d_mv0, d_sad1, d_mv1, n_lists, d_out, stream=None):
+    """Bi-prediction + packing over all 209 PUs; d_out: [n_sb][209] ME_CU_RESULT_DTYPE in raster PU order."""
+    _check(lib().svthip_me_bipred_pack209_dev(self._h, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_ref1, ref1_stride, d_desc1,
+                                              n_sb, max_sw, max_sh, d_sad0, d_mv0, d_sad1, d_mv1, n_lists, d_out, stream))
+
+
+def _motion_estimate209_batch_dev(self, d_pool, curs, refs0, refs1, params, d_sb, n_sb, d_out, use_subpel=True, cu8x8_mode=0,
+                                  d_list_sad=None, d_list_mv=None, stream=None):
+    """Whole-picture ME in the 209-PU mode of len(curs) pictures in one call; refs1=None for P pictures."""
+    n = len(curs)
+    ca, r0 = (PaPictureDesc * n)(*curs), (PaPictureDesc * n)(*refs0)
+    r1 = (PaPictureDesc * n)(*refs1) if refs1 is not None else None
+    _check(lib().svthip_motion_estimate209_batch_dev(self._h, d_pool, ca, r0, r1, n, C.byref(params), int(use_subpel), int(cu8x8_mode),
+                                                     d_sb, n_sb, d_out, d_list_sad, d_list_mv, stream))
+
+
+Context.subpel_refine209_dev = _subpel_refine209_dev
+Context.bipred_pack209_dev = _bipred_pack209_dev
+Context.motion_estimate209_batch_dev = _motion_estimate209_batch_dev
 
 
 def _quantize_b_batch_dev(self, d_coeff, d_desc, n_tu, d_qparams, d_iscan, d_qcoeff, d_dqcoeff, d_eob, stream=None):

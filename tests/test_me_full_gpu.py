@@ -52,6 +52,43 @@ def test_motion_estimate_picture_matches_oracle(hip_ctx, oracle, case):
     compare_results(res_d, res_o)
 
 
+CASES209 = [
+    # w, h, kind, hier, tl, two_lists, use_subpel, cu8x8_mode
+    (320, 192, "pan", 3, 0, False, True, 0),
+    (320, 192, "pan", 3, 1, True, True, 0),
+    (320, 192, "smooth", 3, 1, True, True, 1),    # cu8x8_mode 1: 8x8 PUs keep full-pel MVs but still get a bi-pred candidate
+    (320, 192, "random", 3, 2, True, True, 0),
+    (328, 200, "smooth", 4, 1, True, True, 0),    # partial right column / bottom row
+    (320, 192, "pan", 3, 1, True, False, 0),      # sub-pel off: the configuration pinned against the reference binary
+]
+
+
+@pytest.mark.parametrize("case", CASES209)
+def test_motion_estimate209_matches_oracle(hip_ctx, oracle, case):
+    """The 209-PU (all-partition) mode through svthip_motion_estimate209_batch_dev: HME -> 209-PU full-pel -> sub-pel of
+    squares and rectangles -> bi-prediction and packing of all 209 PUs."""
+    pytest.importorskip("torch")
+    w, h, kind, hier, tl, two, subpel, cu8 = case
+    pics = _pics(w, h, kind)
+    P = svtav1_hip.default_me_params(w, h, hier, tl)
+    res_o, per = oracle_me_picture(oracle, pics, P, two, subpel, cu8, n_pu=209)
+    res_d, ls, lm = device_me_picture(hip_ctx, pics, P, two, subpel, cu8, n_pu=209)
+    for l in per:
+        bad = np.argwhere((ls[l] != per[l][1]) | (lm[l] != per[l][2]))
+        assert bad.size == 0, f"list {l}: {len(bad)} (sb, pu) mismatches, first {bad[0]}, PUs {sorted(set(bad[:, 1].tolist()))[:20]}"
+    compare_results(res_d, res_o)
+
+
+def test_motion_estimate209_squares_equal_85pu_mode(hip_ctx):
+    """The first 85 ME-buffer entries of the 209-PU mode are the 85-PU mode's (same search, same refinement)."""
+    pytest.importorskip("torch")
+    pics = _pics(320, 192, "smooth")
+    P = svtav1_hip.default_me_params(320, 192, 3, 1)
+    _, ls85, lm85 = device_me_picture(hip_ctx, pics, P, True, True, 0)
+    _, ls209, lm209 = device_me_picture(hip_ctx, pics, P, True, True, 0, n_pu=209)
+    assert np.array_equal(ls209[:, :, :85], ls85) and np.array_equal(lm209[:, :, :85], lm85)
+
+
 def test_motion_estimate_picture_1080p_b_picture(hip_ctx, oracle):
     """Full-size B picture through the whole chain; a sample of SBs against the oracle chain."""
     pytest.importorskip("torch")

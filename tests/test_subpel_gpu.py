@@ -88,3 +88,32 @@ def test_subpel_1080p_after_fullpel(hip_ctx, oracle):
     assert (np.abs(x1 - x0) <= 3).all() and (np.abs(y1 - y0) <= 3).all()
     same = m_h == m0
     assert np.array_equal(s_h[same], s0[same])
+
+
+@pytest.mark.parametrize("kind,search", [("smooth", (64, 64)), ("extreme", (23, 9)), ("random", (127, 127)), ("synth", (16, 16))])
+def test_subpel209_matches_oracle(hip_ctx, oracle, kind, search):
+    """svthip_me_subpel_refine209_dev: the 85 squares and the 124 rectangular PUs of the all-partition mode."""
+    torch = pytest.importorskip("torch")
+    w, h = 192, 136
+    cur, ref = _pictures(w, h, kind)
+    rng = np.random.default_rng(21)
+    nx, ny = cur.sb_grid()
+    centers = rng.integers(-30, 31, size=(nx * ny, 2))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, centers, *search)
+    s0, m0 = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    s_o, m_o = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(cur.full).to(dev)
+    d_ref = torch.from_numpy(ref.full).to(dev)
+    d_desc = torch.from_numpy(desc).to(dev)
+    d_sad = torch.from_numpy(s0.view(np.int32).copy()).to(dev)
+    d_mv = torch.from_numpy(m0.view(np.int32).copy()).to(dev)
+    torch.cuda.synchronize()
+    hip_ctx.subpel_refine209_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), desc.shape[0],
+                                 int(desc[:, 4].max()), int(desc[:, 5].max()), d_sad.data_ptr(), d_mv.data_ptr())
+    hip_ctx.synchronize()
+    s_h, m_h = d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
+    bad = np.argwhere((s_h != s_o) | (m_h != m_o))
+    assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}, PUs {sorted(set(bad[:, 1].tolist()))[:24]}"
+    if kind == "smooth":
+        assert (m_o[:, 85:] != m0[:, 85:]).any()  # the refinement moved some rectangular PUs
