@@ -54,6 +54,18 @@ def me_chain_fixture():
                         res=out["res"])
 
 
+def me_chain209_fixture():
+    """MotionEstimateLcu in the 209-PU mode (pic_depth_mode = PIC_ALL_DEPTH_MODE, sub-pel off) on the pictures of
+    me_lcu_b_picture.npz: per-list SAD / MV [n,2,209] in ME-buffer order and me_results [n,209,11] in raster PU order."""
+    refme = ReferenceME()
+    g = np.load(os.path.join(HERE, "me_lcu_b_picture.npz"))
+    pics = [synth.PaPicture(g[k]) for k in ("cur", "ref0", "ref1")]
+    P = svtav1_hip.default_me_params(pics[0].width, pics[0].height, 3, 1)
+    out = refme.run(pics[0], pics[1], pics[2], P, two_lists=True, hierarchical_levels=3, all_pu=True)
+    np.savez_compressed(os.path.join(HERE, "me_lcu_b_picture_209pu.npz"), hierarchical_levels=3, temporal_layer=1, sad=out["sad"],
+                        mv=out["mv"], origin=out["origin"], res=out["res"])
+
+
 def interp_fixture():
     refme = ReferenceME()
     img = np.random.default_rng(7).integers(0, 256, (160, 224), dtype=np.uint8)
@@ -112,6 +124,7 @@ if __name__ == "__main__":
     transform_fixture()
     fullpel_fixture()
     me_chain_fixture()
+    me_chain209_fixture()
     interp_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

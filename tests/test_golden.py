@@ -72,6 +72,39 @@ def test_hip_me_chain_matches_golden(hip_ctx):
     assert np.array_equal(res["direction"][:, :, 1], r[:, :, 7])
 
 
+def _check_chain209(res, ls, lm, g):
+    for l in (0, 1):
+        assert np.array_equal(ls[l], g["sad"][:, l]) and np.array_equal(lm[l], g["mv"][:, l])
+    r = g["res"]  # [n,209,11] = xMvL0,yMvL0,xMvL1,yMvL1, dist0,dir0, dist1,dir1, total, dist2,dir2
+    assert np.array_equal(res["totalMeCandidateIndex"], r[:, :, 8])
+    for f, c in (("xMvL0", 0), ("yMvL0", 1), ("xMvL1", 2), ("yMvL1", 3)):
+        assert np.array_equal(res[f], r[:, :, c]), f
+    for k, (di, dr) in enumerate(((4, 5), (6, 7), (9, 10))):
+        assert np.array_equal(res["distortion"][:, :, k], r[:, :, di].astype(np.uint32)), f"distortion[{k}]"
+        assert np.array_equal(res["direction"][:, :, k], r[:, :, dr]), f"direction[{k}]"
+
+
+def test_oracle_me_chain209_matches_golden(oracle):
+    from me_chain_util import oracle_me_picture
+    gi, g = _load("me_lcu_b_picture.npz"), _load("me_lcu_b_picture_209pu.npz")
+    pics = [synth.PaPicture(gi[k]) for k in ("cur", "ref0", "ref1")]
+    P = svtav1_hip.default_me_params(pics[0].width, pics[0].height, int(g["hierarchical_levels"]), int(g["temporal_layer"]))
+    res, per = oracle_me_picture(oracle, pics, P, True, use_subpel=False, n_pu=209)
+    _check_chain209(res, [per[0][1], per[1][1]], [per[0][2], per[1][2]], g)
+
+
+@pytest.mark.gpu
+def test_hip_me_chain209_matches_golden(hip_ctx):
+    """The reference's own MotionEstimateLcu output in the 209-PU mode (sub-pel off) vs svthip_motion_estimate209_batch_dev."""
+    pytest.importorskip("torch")
+    from me_chain_util import device_me_picture
+    gi, g = _load("me_lcu_b_picture.npz"), _load("me_lcu_b_picture_209pu.npz")
+    pics = [synth.PaPicture(gi[k]) for k in ("cur", "ref0", "ref1")]
+    P = svtav1_hip.default_me_params(pics[0].width, pics[0].height, int(g["hierarchical_levels"]), int(g["temporal_layer"]))
+    res, ls, lm = device_me_picture(hip_ctx, pics, P, True, use_subpel=False, n_pu=209)
+    _check_chain209(res, ls, lm, g)
+
+
 def test_oracle_fullpel209_matches_golden(oracle):
     g = _load("fullpel_209pu.npz")
     cur, ref = synth.PaPicture(g["cur"]), synth.PaPicture(g["ref"])
