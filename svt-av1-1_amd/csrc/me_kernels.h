@@ -34,11 +34,17 @@ __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable 
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                 const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
-                                int disable_8x8, int pu_stride, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv);
+                                int disable_8x8, int pu_stride, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv,
+                                uint32_t* __restrict__ pred_out, int pred_slots);
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                   uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
-                                  uint32_t* __restrict__ io_mv);
+                                  uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out);
+__global__ void bipred_stored_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const int32_t* __restrict__ desc0,
+                                          const uint8_t* __restrict__ pred0, const uint8_t* __restrict__ pred1,
+                                          const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,
+                                          const uint32_t* __restrict__ sad1, const uint32_t* __restrict__ mv1, int n_pu, int bipred_8x8,
+                                          svthip_me_cu_result* __restrict__ out);
 size_t subpel_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void bipred_nsq_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                        const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride, const int32_t* __restrict__ desc0,

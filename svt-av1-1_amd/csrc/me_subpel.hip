@@ -334,10 +334,31 @@ __device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const T& t, in
     }
 }
 
+// prediction sample of one list at fractional position frac = (x_mv & 3) + ((y_mv & 3) << 2); (x,y) = integer position
+// in search-region coordinates.  F = A(x,y), Bq = b(x+1,y), Hq = h(x,y+1), Jq = j(x+1,y+1) are the samples
+// BiPredictionCompensation's buffer indices select (:5155-5158); quarter positions average two of them
+// (QuarterPelCompensation :4844-4910).  Table: two (plane, dx, dy) samples per frac, averaged with rounding; the pure
+// positions list the same sample twice (avg(a, a) = a), so one code path serves every lane group of a wave.
+#define BS(p, dx, dy) ((p) | ((dx) << 2) | ((dy) << 3))
+__device__ const uint8_t kBiFrac[16][2] = {
+    {BS(0, 0, 0), BS(0, 0, 0)}, {BS(0, 0, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(0, 1, 0)},
+    {BS(0, 0, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(3, 1, 1)}, {BS(1, 1, 0), BS(2, 1, 1)},
+    {BS(2, 0, 1), BS(2, 0, 1)}, {BS(2, 0, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(2, 1, 1)},
+    {BS(2, 0, 1), BS(0, 0, 1)}, {BS(2, 0, 1), BS(1, 1, 1)}, {BS(3, 1, 1), BS(1, 1, 1)}, {BS(2, 1, 1), BS(1, 1, 1)}};
+#undef BS
+
+template <class T>
+__device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const T& t, int e0, int e1, int x, int y, int bx, int by)
+{
+    const uint32_t a = plane_sample4(win, t, e0 & 3, x + ((e0 >> 2) & 1), y + ((e0 >> 3) & 1), bx, by);
+    const uint32_t b = plane_sample4(win, t, e1 & 3, x + ((e1 >> 2) & 1), y + ((e1 >> 3) & 1), bx, by);
+    return avg_u8x4(a, b);
+}
+
 // half + quarter for one PW x PH PU at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
 template <int PW, int PH, int LPP>
 __device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW, PH>& t, int px, int py, int xo, int yo, int l,
-                          uint32_t* sad_io, uint32_t* mv_io, int pu)
+                          uint32_t* sad_io, uint32_t* mv_io, int pu, uint32_t* pred_out = nullptr)
 {
     uint32_t bs = sad_io[pu], bm = mv_io[pu], bssd = 0;
     const int x_mv = (int)(int16_t)(bm & 0xffffu), y_mv = (int)(int16_t)(bm >> 16);
@@ -353,6 +374,20 @@ __device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW, PH>& t, i
         sad_io[pu] = bs;
         mv_io[pu] = bm;
     }
+    if (pred_out) {
+        // the prediction block at the refined MV, as BiPredictionCompensation would build it (kBiFrac): the bi-prediction stage
+        // then averages two stored blocks instead of interpolating both lists again.  floor(mv / 4) is the full-pel position or
+        // one sample left / above it, so the tiles of this PU cover every sample the table can ask for.
+        const int fx = (int)(int16_t)(bm & 0xffffu), fy = (int)(int16_t)(bm >> 16);
+        const int f = (fx & 3) + ((fy & 3) << 2);
+        const int e0 = kBiFrac[f][0], e1 = kBiFrac[f][1];
+        const int ix = (fx >> 2) - xo + px, iy = (fy >> 2) - yo + py;
+#pragma unroll 2
+        for (int i = l; i < (PW / 4) * PH; i += LPP) {
+            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
+            pred_out[i] = bipred_sample4(win, t, e0, e1, ix + x, iy + y, bx, by);
+        }
+    }
 }
 
 }  // namespace
@@ -360,7 +395,8 @@ __device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW, PH>& t, i
 __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                        const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                                        const int32_t* __restrict__ desc, int disable_8x8, int pu_stride,
-                                                       uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv)
+                                                       uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv,
+                                                       uint32_t* __restrict__ pred_out, int pred_slots)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -405,27 +441,41 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
     Win win{wbuf, pitch};
     uint32_t* sad_io = io_sad + (size_t)pu_stride * blockIdx.x;  // [n_sb][pu_stride], the squares are entries 0..84
     uint32_t* mv_io = io_mv + (size_t)pu_stride * blockIdx.x;
+    // optional prediction store: [n_sb][pred_slots][1024 dwords], slot 0 = 64x64, 1 = 32x32, 2 = 16x16, 3 = 8x8, PUs in raster order
+    uint32_t* pred = pred_out ? pred_out + (size_t)blockIdx.x * pred_slots * 1024 : nullptr;
 
     if (wave == 0) {
         Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-        refine_pu<64, 64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0);
+        refine_pu<64, 64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0, pred);
     } else if (wave == 1) {
         lds_u8* b = tile_base + t64;
         Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
-        for (int p = 0; p < 4; p++) refine_pu<32, 32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p);
+        for (int p = 0; p < 4; p++)
+            refine_pu<32, 32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p,
+                                  pred ? pred + 1024 + p * 256 : nullptr);
     } else if (wave == 2) {
         lds_u8* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
         Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
         for (int pass = 0; pass < 4; pass++) {
             const int p = pass * 4 + (lane >> 4);
-            refine_pu<16, 16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p]);
+            refine_pu<16, 16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p],
+                                  pred ? pred + 2048 + p * 64 : nullptr);
         }
     } else if (!disable_8x8) {
         lds_u8* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
         Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
         for (int pass = 0; pass < 8; pass++) {
             const int p = pass * 8 + (lane >> 3);
-            refine_pu<8, 8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p]);
+            refine_pu<8, 8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p],
+                               pred ? pred + 3072 + p * 16 : nullptr);
+        }
+    } else if (pred) {
+        // cu8x8_mode 1: the 8x8 PUs keep their full-pel MVs; the 209-PU mode still bi-predicts them, from the integer samples
+        for (int i = lane; i < 1024; i += 64) {
+            const int p = i >> 4, y = (i >> 1) & 7, x = (i & 1) * 4;
+            const uint32_t m = mv_io[21 + kTab8[p]];
+            const int ix = ((int)(int16_t)(m & 0xffffu) >> 2) - xo + ((p & 7) << 3) + x, iy = ((int)(int16_t)(m >> 16) >> 2) - yo + ((p >> 3) << 3) + y;
+            pred[3072 + i] = lds_u32_at(win.p + (iy + kMargin) * win.pitch + ix + kMargin);
         }
     }
 }
@@ -434,27 +484,6 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
 // Bi-prediction SAD + result packing (Codec/EbMotionEstimation.c:6973-7146).
 // ------------------------------------------------------------------------------------------------------------
 namespace {
-
-// prediction sample of one list at fractional position frac = (x_mv & 3) + ((y_mv & 3) << 2); (x,y) = integer position
-// in search-region coordinates.  F = A(x,y), Bq = b(x+1,y), Hq = h(x,y+1), Jq = j(x+1,y+1) are the samples
-// BiPredictionCompensation's buffer indices select (:5155-5158); quarter positions average two of them
-// (QuarterPelCompensation :4844-4910).  Table: two (plane, dx, dy) samples per frac, averaged with rounding; the pure
-// positions list the same sample twice (avg(a, a) = a), so one code path serves every lane group of a wave.
-#define BS(p, dx, dy) ((p) | ((dx) << 2) | ((dy) << 3))
-__device__ const uint8_t kBiFrac[16][2] = {
-    {BS(0, 0, 0), BS(0, 0, 0)}, {BS(0, 0, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(1, 1, 0)}, {BS(1, 1, 0), BS(0, 1, 0)},
-    {BS(0, 0, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(2, 0, 1)}, {BS(1, 1, 0), BS(3, 1, 1)}, {BS(1, 1, 0), BS(2, 1, 1)},
-    {BS(2, 0, 1), BS(2, 0, 1)}, {BS(2, 0, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(3, 1, 1)}, {BS(3, 1, 1), BS(2, 1, 1)},
-    {BS(2, 0, 1), BS(0, 0, 1)}, {BS(2, 0, 1), BS(1, 1, 1)}, {BS(3, 1, 1), BS(1, 1, 1)}, {BS(2, 1, 1), BS(1, 1, 1)}};
-#undef BS
-
-template <class T>
-__device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const T& t, int e0, int e1, int x, int y, int bx, int by)
-{
-    const uint32_t a = plane_sample4(win, t, e0 & 3, x + ((e0 >> 2) & 1), y + ((e0 >> 3) & 1), bx, by);
-    const uint32_t b = plane_sample4(win, t, e1 & 3, x + ((e1 >> 2) & 1), y + ((e1 >> 3) & 1), bx, by);
-    return avg_u8x4(a, b);
-}
 
 // bi-pred SAD of one PW x PH PU per group of LPP lanes: list-0 prediction goes through `pred0` (PW*PH bytes of LDS per group)
 // so the tile memory can be reused for list 1
@@ -562,7 +591,7 @@ __device__ constexpr int kNsqPredOff[kNsqRoles + 1] = {0, 2048, 3072, 4096, 5120
 // sub-pel refinement of the `count` PUs of one shape class starting at raster PU index `base`, 64 / LPP of them per pass
 template <int PW, int PH, int LPP>
 __device__ void refine_class(const lds_u8* src, const Win& win, lds_u8* tiles, int xo, int yo, int lane, uint32_t* sad_io, uint32_t* mv_io,
-                             int base, int count)
+                             int base, int count, uint32_t* pred)  // pred: this class' 1024-dword prediction slot, or null
 {
     constexpr int G = 64 / LPP;
     const int g = lane / LPP, l = lane % LPP;
@@ -570,7 +599,7 @@ __device__ void refine_class(const lds_u8* src, const Win& win, lds_u8* tiles, i
 #pragma unroll 1
     for (int p = g; p < count; p += G) {
         const int pu = base + p;
-        refine_pu<PW, PH, LPP>(src, win, t, kPu.px[pu], kPu.py[pu], xo, yo, l, sad_io, mv_io, kPu.me[pu]);
+        refine_pu<PW, PH, LPP>(src, win, t, kPu.px[pu], kPu.py[pu], xo, yo, l, sad_io, mv_io, kPu.me[pu], pred ? pred + p * (PW * PH / 4) : nullptr);
     }
 }
 
@@ -727,7 +756,7 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
 __global__ void __launch_bounds__(320) subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                          const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                                          const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
-                                                         uint32_t* __restrict__ io_mv)
+                                                         uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -749,22 +778,27 @@ __global__ void __launch_bounds__(320) subpel_nsq_kernel(const uint8_t* __restri
     uint32_t* sad_io = io_sad + (size_t)209 * blockIdx.x;
     uint32_t* mv_io = io_mv + (size_t)209 * blockIdx.x;
     lds_u8* tiles = tile_base + kNsqTileOff[role];
+    // optional prediction store: [n_sb][14 slots][1024 dwords]; slots 4..13 = the rectangular classes in ME-buffer order
+    // (64x32, 32x16, 16x8, 32x64, 16x32, 8x16, 32x8, 8x32, 64x16, 16x64), PUs in raster order inside a slot
+    uint32_t* pred = pred_out ? pred_out + (size_t)blockIdx.x * 14 * 1024 : nullptr;
+#define SLOT(k) (pred ? pred + (k) * 1024 : nullptr)
     if (role == 0) {
-        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2);
-        refine_class<32, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 127, 2);
+        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2, SLOT(4));
+        refine_class<32, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 127, 2, SLOT(7));
     } else if (role == 1) {
-        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4);
-        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4);
+        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4, SLOT(12));
+        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4, SLOT(13));
     } else if (role == 2) {
-        refine_class<32, 16, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 87, 8);
-        refine_class<16, 32, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 129, 8);
+        refine_class<32, 16, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 87, 8, SLOT(5));
+        refine_class<16, 32, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 129, 8, SLOT(8));
     } else if (role == 3) {
-        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16);
-        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16);
+        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16, SLOT(10));
+        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16, SLOT(11));
     } else {
-        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32);
-        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32);
+        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32, SLOT(6));
+        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32, SLOT(9));
     }
+#undef SLOT
 }
 
 // 209-PU mode: bi-prediction SADs of the rectangular PUs, then packing of all 209 PUs (:6973-7146; in this mode every PU
@@ -834,6 +868,82 @@ __global__ void __launch_bounds__(320) bipred_nsq_pack_kernel(const uint8_t* __r
     if (tid < 209) {
         const int pu = tid, n = kPu.me[pu];  // me_results[sb][pu] in raster PU order; n = ME-buffer index (:6980-7015)
         out[209 * sb + pu] = pack_result(s0[n], m0[n], n_lists == 2 ? s1[n] : 0u, m1[n], n_lists == 2 ? bisad[n] : 0u, n_lists, n_lists == 2 ? 3 : 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Bi-prediction from the predictions the sub-pel kernels stored (pred0 / pred1 = [n_sb][slots][4096 bytes], one per list):
+// SAD(src, avg(P0, P1)) per PU, then packing.  No interpolation, no window: 8 KB of reads per shape class.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int W, int H, int BASE, int COLS, int SLOT>
+__device__ __forceinline__ void bipred_stored_class(const lds_u8* src, const uint4* __restrict__ p0, const uint4* __restrict__ p1,
+                                                    uint32_t* bisad, int tid)
+{
+    // thread tid owns bytes [16 tid, 16 tid + 16) of the class' 4096 prediction bytes (PUs in raster order, rows of W bytes)
+    const uint4 a = p0[SLOT * 256 + tid], b = p1[SLOT * 256 + tid];
+    constexpr int PB = W * H;
+    const int p = (16 * tid) / PB, w = (16 * tid) % PB;
+    const int px = (p % COLS) * W, py = (p / COLS) * H;
+    const uint32_t av[4] = {avg_u8x4(a.x, b.x), avg_u8x4(a.y, b.y), avg_u8x4(a.z, b.z), avg_u8x4(a.w, b.w)};
+    uint32_t sad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int o = w + 4 * k, y = o / W, x = o % W;
+        sad = __builtin_amdgcn_sad_u8(*reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x), av[k], sad);
+    }
+    constexpr int R = PB / 16 < 64 ? PB / 16 : 64;  // lanes of a wave that share a PU
+    sad = gsum<R>(sad);
+    if ((tid & (R - 1)) == 0) atomicAdd(&bisad[kPu.me[BASE + p]], sad);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) bipred_stored_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+                                                                 const int32_t* __restrict__ desc0, const uint8_t* __restrict__ pred0,
+                                                                 const uint8_t* __restrict__ pred1, const uint32_t* __restrict__ sad0,
+                                                                 const uint32_t* __restrict__ mv0, const uint32_t* __restrict__ sad1,
+                                                                 const uint32_t* __restrict__ mv1, int n_pu, int bipred_8x8,
+                                                                 svthip_me_cu_result* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t src_raw[4096];
+    __shared__ uint32_t bisad[209];  // indexed by ME-buffer PU index
+    const int tid = threadIdx.x;
+    const size_t sb = blockIdx.x;
+    lds_u8* src = (lds_u8*)src_raw;
+    const int32_t* d0 = desc0 + 6 * sb;
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int r = i >> 4, c = i & 15;
+        reinterpret_cast<lds_u32*>(src)[i] = *reinterpret_cast<const uint32_t*>(src_plane + d0[0] + (size_t)r * src_stride + 4 * c);
+    }
+    if (tid < 209) bisad[tid] = 0;
+    __syncthreads();
+    const int slots = n_pu == 209 ? 14 : 4;
+    const uint4* p0 = reinterpret_cast<const uint4*>(pred0 + sb * slots * 4096);
+    const uint4* p1 = reinterpret_cast<const uint4*>(pred1 + sb * slots * 4096);
+    bipred_stored_class<64, 64, 0, 1, 0>(src, p0, p1, bisad, tid);
+    bipred_stored_class<32, 32, 1, 2, 1>(src, p0, p1, bisad, tid);
+    bipred_stored_class<16, 16, 5, 4, 2>(src, p0, p1, bisad, tid);
+    if (bipred_8x8 || n_pu == 209) bipred_stored_class<8, 8, 21, 8, 3>(src, p0, p1, bisad, tid);
+    if (n_pu == 209) {
+        bipred_stored_class<64, 32, 85, 1, 4>(src, p0, p1, bisad, tid);
+        bipred_stored_class<32, 16, 87, 2, 5>(src, p0, p1, bisad, tid);
+        bipred_stored_class<16, 8, 95, 4, 6>(src, p0, p1, bisad, tid);
+        bipred_stored_class<32, 64, 127, 2, 7>(src, p0, p1, bisad, tid);
+        bipred_stored_class<16, 32, 129, 4, 8>(src, p0, p1, bisad, tid);
+        bipred_stored_class<8, 16, 137, 8, 9>(src, p0, p1, bisad, tid);
+        bipred_stored_class<32, 8, 169, 2, 10>(src, p0, p1, bisad, tid);
+        bipred_stored_class<8, 32, 185, 8, 11>(src, p0, p1, bisad, tid);
+        bipred_stored_class<64, 16, 201, 1, 12>(src, p0, p1, bisad, tid);
+        bipred_stored_class<16, 64, 205, 4, 13>(src, p0, p1, bisad, tid);
+    }
+    __syncthreads();
+    if (tid < n_pu) {
+        const int pu = tid, n = kPu.me[pu];
+        const bool bi = bipred_8x8 || pu < 21 || n_pu == 209;  // :7028
+        out[(size_t)n_pu * sb + pu] = pack_result(sad0[(size_t)n_pu * sb + n], mv0[(size_t)n_pu * sb + n], sad1[(size_t)n_pu * sb + n],
+                                                  mv1[(size_t)n_pu * sb + n], bi ? bisad[n] : 0u, 2, bi ? 3 : 2);
     }
 }
 

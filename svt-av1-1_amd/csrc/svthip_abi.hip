@@ -141,7 +141,7 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
 static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
                                      uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_search_area_width,
                                      uint32_t max_search_area_height, int32_t disable_8x8_refinement, int n_pu, uint32_t* d_best_sad,
-                                     uint32_t* d_best_mv, void* stream)
+                                     uint32_t* d_best_mv, void* stream, uint32_t* d_pred = nullptr)
 {
     if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
     if (n_sb == 0) return SVTHIP_OK;
@@ -159,13 +159,13 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv);
+                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv, d_pred, n_pu == 209 ? 14 : 4);
     HIP_TRY(hipGetLastError());
     if (n_pu == 209) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nsq));
         hipLaunchKernelGGL(svthip::subpel_nsq_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                           reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv);
+                           reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv, d_pred);
         HIP_TRY(hipGetLastError());
     }
     return SVTHIP_OK;
@@ -522,6 +522,15 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
     const uint32_t sw = params->search_area_width < 127 ? params->search_area_width : 127;
     const uint32_t sh = params->search_area_height < 127 ? params->search_area_height : 127;
     const svthip_pa_picture* refs[2] = {ref0, ref1};
+    // B pictures with sub-pel on: the sub-pel kernels also store each PU's prediction at its refined MV (scratch slot 7,
+    // [2 lists][n][slots][4096 bytes]) and the bi-prediction stage averages the stored blocks instead of interpolating again
+    const size_t pred_b = (size_t)(n_pu == 209 ? 14 : 4) * 4096 * n;
+    uint8_t* pred[2] = {nullptr, nullptr};
+    if (n_lists == 2 && use_subpel_flag) {
+        if ((rc = ensure_scratch(ctx, 7, 2 * pred_b))) return rc;
+        pred[0] = static_cast<uint8_t*>(ctx->scratch[7]);
+        pred[1] = pred[0] + pred_b;
+    }
     // seven launches whatever the number of pictures: per list search centres -> full-pel -> sub-pel, then bi-prediction + packing
     for (uint32_t l = 0; l < n_lists; l++) {
         if ((rc = svthip_me_hme_search_center_batch_dev(ctx, d_pool, cur, refs[l], n_jobs, params, l, d_sb, n_sb, l ? mv[0] : nullptr, n_pu,
@@ -533,8 +542,16 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
         if (rc) return rc;
         if (use_subpel_flag &&
             (rc = subpel_refine_common(ctx, d_pool, cur->full_stride, d_pool, refs[l]->full_stride, desc[l], (uint32_t)n, sw, sh,
-                                       cu8x8_mode == 1, (int)n_pu, sad[l], mv[l], s)))
+                                       cu8x8_mode == 1, (int)n_pu, sad[l], mv[l], s, reinterpret_cast<uint32_t*>(pred[l]))))
             return rc;
+    }
+    if (pred[0]) {
+        hipLaunchKernelGGL(svthip::bipred_stored_pack_kernel, dim3((uint32_t)n), dim3(256), 0, s, d_pool, cur->full_stride,
+                           reinterpret_cast<const int32_t*>(desc[0]), (const uint8_t*)pred[0], (const uint8_t*)pred[1],
+                           (const uint32_t*)sad[0], (const uint32_t*)mv[0], (const uint32_t*)sad[1], (const uint32_t*)mv[1], (int)n_pu,
+                           (int)(cu8x8_mode == 0), d_out);
+        HIP_TRY(hipGetLastError());
+        return SVTHIP_OK;
     }
     return bipred_pack_common(ctx, d_pool, cur->full_stride, d_pool, ref0->full_stride, desc[0], n_lists == 2 ? d_pool : nullptr,
                               n_lists == 2 ? ref1->full_stride : 0, n_lists == 2 ? desc[1] : nullptr, (uint32_t)n, sw, sh, sad[0], mv[0],
