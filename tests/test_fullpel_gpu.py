@@ -176,3 +176,16 @@ def test_me_entries_reject_bad_arguments(hip_ctx):
     P = svtav1_hip.default_me_params(128, 64, 3, 0)
     with pytest.raises(svtav1_hip.SvtHipError, match="list_index"):
         hip_ctx.hme_search_center_dev(d_pool.data_ptr(), pd[1], pd[0], P, 2, sb.data_ptr(), 2, None, out.data_ptr())
+    # the 209-PU sub-pel / bi-pred / whole-chain entries validate like their 85-PU counterparts
+    with pytest.raises(svtav1_hip.SvtHipError, match="search area"):
+        hip_ctx.subpel_refine209_dev(p, 256, p, 256, p, 1, 128, 64, out.data_ptr(), out.data_ptr())
+    with pytest.raises(svtav1_hip.SvtHipError, match="null"):
+        hip_ctx.subpel_refine209_dev(p, 256, p, 256, p, 1, 64, 64, None, out.data_ptr())
+    with pytest.raises(svtav1_hip.SvtHipError, match="n_lists"):
+        hip_ctx.bipred_pack209_dev(p, 256, p, 256, p, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr(), out.data_ptr(), out.data_ptr(), 3,
+                                   out.data_ptr())
+    hip_ctx.subpel_refine209_dev(p, 256, p, 256, p, 0, 64, 64, out.data_ptr(), out.data_ptr())
+    other = svtav1_hip.PaPictureDesc.from_buffer_copy(pd[1])
+    other.full_stride += 4  # pictures of one batch must share their strides
+    with pytest.raises(svtav1_hip.SvtHipError, match="strides"):
+        hip_ctx.motion_estimate209_batch_dev(d_pool.data_ptr(), [pd[1], other], [pd[0], pd[0]], None, P, sb.data_ptr(), 2, out.data_ptr())
