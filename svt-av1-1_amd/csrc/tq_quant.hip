@@ -36,8 +36,7 @@ __global__ void __launch_bounds__(256) quantize_b_batch_kernel(const int32_t* __
         const int16_t* qp = qparams + (size_t)d.qparam_index * 10;
         const int16_t* iscan = iscan_pool + d.iscan_offset;
         const int log_scale = d.log_scale, highbd = d.highbd;
-        const int32_t zb[2] = {rpot(qp[0], log_scale), rpot(qp[1], log_scale)};
-        const int32_t rnd[2] = {rpot(qp[2], log_scale), rpot(qp[3], log_scale)};
+        const QParams QP = load_qparams(qp, log_scale);
         const int32_t* cin = coeff + d.coeff_offset;
         int32_t* qo = qcoeff + d.coeff_offset;
         int32_t* dqo = dqcoeff + d.coeff_offset;
@@ -51,7 +50,7 @@ __global__ void __launch_bounds__(256) quantize_b_batch_kernel(const int32_t* __
             int32_t qv[4], dqv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                quant_one(cv[k], (base + k) != 0, zb, rnd, qp, log_scale, highbd, qv[k], dqv[k]);
+                quant_one(cv[k], (base + k) != 0, QP, log_scale, highbd, qv[k], dqv[k]);
                 if (qv[k] != 0) last = max(last, isv[k] + 1);
             }
             *reinterpret_cast<int4*>(qo + base) = make_int4(qv[0], qv[1], qv[2], qv[3]);

@@ -5,20 +5,55 @@
 
 __device__ __forceinline__ int32_t rpot(int32_t v, int n) { return n == 0 ? v : ((v + (1 << (n - 1))) >> n); }
 
-__device__ __forceinline__ void quant_one(int32_t c, int ac, const int32_t* zb, const int32_t* rnd, const int16_t* qp, int log_scale,
-                                          int highbd, int32_t& q, int32_t& dq)
+// a * b + acc with a 64-bit accumulator: one v_mad_i64_i32 (written as C++ the compiler widens the operands first and
+// builds the product from 32-bit pieces, several instructions and register pairs per product)
+__device__ __forceinline__ int64_t mad64(int32_t a, int32_t b, int64_t acc)
+{
+    int64_t r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+    return r;
+}
+
+// the ten quantiser parameters of a TU, loaded once: {zbin, round, quant, quant_shift, dequant} x {DC, AC}
+struct QParams {
+    int32_t zb[2], rnd[2], quant[2], shift[2], deq[2];
+};
+__device__ __forceinline__ QParams load_qparams(const int16_t* qp, int log_scale)
+{
+    QParams q;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        q.zb[i] = rpot(qp[i], log_scale);
+        q.rnd[i] = rpot(qp[2 + i], log_scale);
+        q.quant[i] = qp[4 + i];  // SIGNED int16: negative for quantisers above 32767
+        q.shift[i] = qp[6 + i];
+        q.deq[i] = qp[8 + i];
+    }
+    return q;
+}
+
+__device__ __forceinline__ void quant_one(int32_t c, int ac, const QParams& P, int log_scale, int highbd, int32_t& q, int32_t& dq)
 {
     const int32_t sign = c >> 31;
     const int32_t abs_c = (c ^ sign) - sign;
     q = 0;
     dq = 0;
-    if (abs_c >= zb[ac]) {
-        long long tmp = (long long)abs_c + rnd[ac];
-        if (!highbd) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX); tmp >= 0 here
-        tmp *= 32;
-        const int32_t level = (int32_t)(((((tmp * qp[4 + ac]) >> 16) + tmp) * qp[6 + ac]) >> (16 - log_scale + 5));
+    if (abs_c >= P.zb[ac]) {
+        int32_t level;
+        if (!highbd) {
+            // 8-bit path: tmp = clamp(abs + round, INT16) * 32 < 2^20, so both products are exact 32 x 32 -> 64-bit
+            // multiplies and the sums stay below 2^21
+            const int32_t t = min(abs_c + P.rnd[ac], 32767) << 5;
+            const int32_t s1 = (int32_t)(mad64(t, P.quant[ac], 0) >> 16) + t;
+            level = (int32_t)(mad64(s1, P.shift[ac], 0) >> (16 - log_scale + 5));
+        } else {
+            long long tmp = (long long)abs_c + P.rnd[ac];
+            if (!highbd) tmp = tmp > 32767 ? 32767 : tmp;  // clamp(.., INT16_MIN, INT16_MAX); tmp >= 0 here
+            tmp *= 32;
+            level = (int32_t)(((((tmp * P.quant[ac]) >> 16) + tmp) * P.shift[ac]) >> (16 - log_scale + 5));
+        }
         q = (level ^ sign) - sign;
-        const int32_t abs_dq = (int32_t)((uint32_t)level * (uint32_t)(int32_t)qp[8 + ac]) >> log_scale;
+        const int32_t abs_dq = (int32_t)((uint32_t)level * (uint32_t)P.deq[ac]) >> log_scale;
         dq = (abs_dq ^ sign) - sign;
     }
 }
