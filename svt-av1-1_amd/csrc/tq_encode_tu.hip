@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ 
 #pragma unroll
                 for (int c = 0; c < W; c++) {
                     y[c] = shift_val<SH2>(y[c]);
-                    if constexpr (RECT2) y[c] = rs<12>((int64_t)y[c] * 5793);
+                    if constexpr (RECT2) y[c] = mulrs<12>(y[c], 5793);
                 }
                 if constexpr (W > 32 || H > 32) {
                     int64_t e4[4] = {0, 0, 0, 0};  // four independent chains: a single one would serialise on the mad latency
@@ -170,7 +170,7 @@ if constexpr (H > 32) {
 #pragma unroll
                     for (int c = 0; c < WIN; c++) {
                         int32_t v = dq[c];
-                        if constexpr (RECT2) v = rs<12>((int64_t)v * 2896);
+                        if constexpr (RECT2) v = mulrs<12>(v, 2896);
                         xi[c] = cl_in(v);
                     }
 #pragma unroll

@@ -132,9 +132,9 @@ __device__ __forceinline__ void fidentity(const int32_t* x, int32_t* out)
 {
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        if constexpr (N == 4) out[i] = rs<12>((int64_t)x[i] * 5793);
+        if constexpr (N == 4) out[i] = mulrs<12>(x[i], 5793);
         else if constexpr (N == 8) out[i] = x[i] * 2;
-        else if constexpr (N == 16) out[i] = rs<12>((int64_t)x[i] * (2 * 5793));
+        else if constexpr (N == 16) out[i] = mulrs<12>(x[i], 2 * 5793);
         else out[i] = x[i] * 4;
     }
 }

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
 #pragma unroll
                     for (int c = 0; c < W; c++) {
                         int32_t v = shift_val<SH2>(y[c]);
-                        if constexpr (RECT2) v = rs<12>((int64_t)v * 5793);
+                        if constexpr (RECT2) v = mulrs<12>(v, 5793);
                         orow[c] = v;
                     }
                 } else {
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             v[k] = shift_val<SH2>(y[c + k]);
-                            if constexpr (RECT2) v[k] = rs<12>((int64_t)v[k] * 5793);
+                            if constexpr (RECT2) v[k] = mulrs<12>(v[k], 5793);
                         }
                         *reinterpret_cast<int4*>(out + c) = make_int4(v[0], v[1], v[2], v[3]);
                     }

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
                 }
 #pragma unroll
                 for (int c = 0; c < WIN; c++) {
-                    if constexpr (RECT2) x[c] = rs<12>((int64_t)x[c] * 2896);
+                    if constexpr (RECT2) x[c] = mulrs<12>(x[c], 2896);
                     x[c] = cl_in(x[c]);
                 }
 #pragma unroll

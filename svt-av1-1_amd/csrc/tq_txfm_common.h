@@ -31,6 +31,16 @@ __device__ __forceinline__ int32_t hb(int32_t w0, int32_t a, int32_t w1, int32_t
     asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(u) : "s"(w1), "v"(b), "v"(t) : "vcc");
     return (int32_t)__builtin_amdgcn_alignbit((uint32_t)(u >> 32), (uint32_t)u, BIT);
 }
+// round_shift(w * v, BIT) with a 64-bit product (the 5793 / 2896 scalings of 2:1 rectangles and identity transforms): one
+// v_mad_i64_i32 with the rounding constant as accumulator + one v_alignbit_b32 (the compiler's own expansion is five)
+template <int BIT>
+__device__ __forceinline__ int32_t mulrs(int32_t v, int32_t w)
+{
+    const int64_t rnd = (int64_t)1 << (BIT - 1);
+    int64_t t;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(t) : "s"(w), "v"(v), "v"(rnd) : "vcc");
+    return (int32_t)__builtin_amdgcn_alignbit((uint32_t)(t >> 32), (uint32_t)t, BIT);
+}
 template <int BIT>
 __device__ __forceinline__ int32_t rs(int64_t v)
 {
