@@ -11,7 +11,8 @@
 // pixel: 1 B source + 1 B prediction + 2 B inverse-scan index in, 4 B quantised coefficient + 1 B reconstruction out
 // (+ 4 B each for the optional transform / dequantised outputs), against 28 B for the five separate passes.
 //
-// Mapping: a wave owns G = 64 / max(W, H) TUs.
+// Mapping: a wave owns G = 64 / min(W, H) TUs, so the pass over the SHORTER dimension's lanes fills the wave exactly and the pass
+// over the longer one takes max / min rounds of 64 lanes (with G = 64 / max the 4:1 rectangles ran one pass at 25 % of the lanes).
 //   A  lane = (tu, column): residual column -> forward column network -> LDS tile
 //   B  lane = (tu, row):    forward row network -> coefficients (registers) -> energy of the dropped part of 64-point
 //                           dimensions, quantiser, distortion, eob (reductions across the TU's lanes) -> inverse row
@@ -61,7 +62,8 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ 
                                                         uint64_t* __restrict__ energy_out, uint64_t* __restrict__ dist_out)
 {
     constexpr int W = 1 << WL, H = 1 << HL, WI = WL - 2, HI = HL - 2;
-    constexpr int MAXD = W > H ? W : H, G = 64 / MAXD, P = W + 1;
+    constexpr int MIND = W < H ? W : H, G = 64 / MIND, P = W + 1;
+    constexpr int ROUNDS_COL = G * W / 64, ROUNDS_ROW = G * H / 64;  // rounds of 64 (tu, column) / (tu, row) lanes
     constexpr int WIN = W > 32 ? 32 : W, HIN = H > 32 ? 32 : H;
     constexpr int SH0 = kShift[WI][HI][0], SH1 = kShift[WI][HI][1], SH2 = kShift[WI][HI][2];
     constexpr int BITC = kCosCol[WI][HI], BITR = kCosRow[WI][HI];
@@ -78,10 +80,11 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ 
     const uint32_t groups = (n_tu + G - 1) / G;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
         // ---- A: residual + forward column pass ----
-        {
-            const int g = lane / W, c = lane % W;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_COL; round++) {
+            const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu) {
+            if (tu < n_tu) {
                 const svthip_tu_desc d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const PIX* s = src + d.src_offset + c;
@@ -103,10 +106,11 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- B: forward row pass, quantiser, inverse row pass ----
-        {
-            const int g = lane / H, r = lane % H;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_ROW; round++) {
+            const int t = round * 64 + lane, g = t / H, r = t % H;
             const uint32_t tu = grp * G + g;
-            const bool active = g < G && tu < n_tu;
+            const bool active = tu < n_tu;
             int64_t energy = 0, dist_res = 0, dist_pred = 0;  // sums of squares: non-negative, below 2^63
             int last = 0;
             if (active) {
@@ -201,10 +205,11 @@ if constexpr (H > 32) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- C: inverse column pass + reconstruction ----
-        {
-            const int g = lane / W, c = lane % W;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_COL; round++) {
+            const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu) {
+            if (tu < n_tu) {
                 const svthip_tu_desc d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const int32_t* col = tile + g * (H * P) + (kr == 2 ? W - 1 - c : c);
@@ -238,7 +243,7 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
                       const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
                       uint64_t* energy, uint64_t* dist, hipStream_t s)
 {
-    constexpr int W = 1 << WL, H = 1 << HL, MAXD = W > H ? W : H, G = 64 / MAXD;
+    constexpr int W = 1 << WL, H = 1 << HL, MIND = W < H ? W : H, G = 64 / MIND;
     constexpr size_t lds = (size_t)4 * G * H * (W + 1) * sizeof(int32_t);
     const uint32_t groups = (n_tu + G - 1) / G;
     uint32_t blocks = (groups + 3) / 4;
