@@ -5,7 +5,8 @@
 // Av1TransformConfig (:3847-3867), with the 1-D networks av1_fdct{4,8,16,32,64}_new (:1314-2762),
 // av1_fadst{4,8,16}_new (:2764-3183) and av1_fidentity{4,8,16,32}_c.
 //
-// Mapping.  One launch handles TUs of one size W x H.  A wave owns G = 64 / max(W, H) TUs at a time:
+// Mapping.  One launch handles TUs of one size W x H.  A wave owns G = 64 / min(W, H) TUs at a time, so the pass whose lanes
+// run along the shorter dimension fills the wave exactly and the other pass takes max / min rounds of 64 lanes:
 //   column pass: lane = (tu, column); the lane loads its H residuals (2-byte loads, a row of a TU is contiguous across lanes),
 //                runs the whole 1-D network in registers (every index is a compile-time constant, so the arrays below are
 //                VGPRs) and writes the rounded column into the wave's LDS tile (pitch W + 1 words: conflict-free both ways);
@@ -36,7 +37,8 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
                                                          uint32_t n_tu, int32_t* __restrict__ coeff)
 {
     constexpr int W = 1 << WL, H = 1 << HL, WI = WL - 2, HI = HL - 2;
-    constexpr int MAXD = W > H ? W : H, G = 64 / MAXD, P = W + 1;
+    constexpr int MIND = W < H ? W : H, G = 64 / MIND, P = W + 1;  // a wave owns 64 / min(W, H) TUs: see tq_encode_tu.hip
+    constexpr int ROUNDS_COL = G * W / 64, ROUNDS_ROW = G * H / 64;
     constexpr int SH0 = kShift[WI][HI][0], SH1 = kShift[WI][HI][1], SH2 = kShift[WI][HI][2];
     constexpr int BITC = kCosCol[WI][HI], BITR = kCosRow[WI][HI];
     constexpr bool RECT2 = (WL - HL == 1) || (HL - WL == 1);
@@ -48,10 +50,11 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
     const uint32_t groups = (n_tu + G - 1) / G;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
         // ---- column pass ----
-        {
-            const int g = lane / W, c = lane % W;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_COL; round++) {
+            const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu) {
+            if (tu < n_tu) {
                 const svthip_txfm_desc d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const int16_t* in = residual + d.in_offset + c;
@@ -69,10 +72,11 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- row pass ----
-        {
-            const int g = lane / H, r = lane % H;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_ROW; round++) {
+            const int t = round * 64 + lane, g = t / H, r = t % H;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu) {
+            if (tu < n_tu) {
                 const svthip_txfm_desc d = desc[tu];
                 const int kr = kHtx[d.tx_type & 15];
                 const int32_t* row = tile + g * (H * P) + r * P;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) fwd_txfm2d_kernel(const int16_t* __restri
 template <int WL, int HL>
 hipError_t launch_one(const int16_t* residual, const svthip_txfm_desc* desc, uint32_t n_tu, int32_t* coeff, hipStream_t s)
 {
-    constexpr int W = 1 << WL, H = 1 << HL, MAXD = W > H ? W : H, G = 64 / MAXD;
+    constexpr int W = 1 << WL, H = 1 << HL, MIND = W < H ? W : H, G = 64 / MIND;
     constexpr size_t lds = (size_t)4 * G * H * (W + 1) * sizeof(int32_t);
     const uint32_t groups = (n_tu + G - 1) / G;
     uint32_t blocks = (groups + 3) / 4;

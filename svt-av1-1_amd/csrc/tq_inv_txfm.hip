@@ -5,7 +5,8 @@
 // (:7590-7616), reached from Av1InvTransformRecon / Av1InvTransformRecon8bit (:8344-8399) through highbd_inv_txfm_add
 // (:8252-8320); 1-D networks av1_idct{4..64}_new (:4902-7000), av1_iadst{4,8,16}_new (:5560-6100), av1_iidentity*_c.
 //
-// Mapping (mirror of tq_fwd_txfm.hip).  A wave owns G = 64 / max(W, H) TUs at a time:
+// Mapping (mirror of tq_fwd_txfm.hip).  A wave owns G = 64 / min(W, H) TUs at a time (the pass over the longer dimension takes
+// max / min rounds of 64 lanes):
 //   row pass:    lane = (tu, row); loads its min(W,32) dequantised coefficients (64-point dimensions are stored packed
 //                32 wide / 32 high, the rest is zero -- :7736-7760 -- so rows >= 32 are skipped and the upper inputs are
 //                compile-time zeros), 1/sqrt(2) pre-scaling for 2:1 rectangles, clamp to bd+8 bits, row network in
@@ -33,7 +34,8 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
                                                              uint32_t n_tu, int bd, PIX* __restrict__ recon)
 {
     constexpr int W = 1 << WL, H = 1 << HL, WI = WL - 2, HI = HL - 2;
-    constexpr int MAXD = W > H ? W : H, G = 64 / MAXD, P = W + 1;
+    constexpr int MIND = W < H ? W : H, G = 64 / MIND, P = W + 1;  // a wave owns 64 / min(W, H) TUs: see tq_encode_tu.hip
+    constexpr int ROUNDS_COL = G * W / 64, ROUNDS_ROW = G * H / 64;
     constexpr int WIN = W > 32 ? 32 : W, HIN = H > 32 ? 32 : H;
     constexpr int SH0 = kInvShift0[WI][HI];
     constexpr bool RECT2 = (WL - HL == 1) || (HL - WL == 1);
@@ -48,10 +50,11 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
     const uint32_t groups = (n_tu + G - 1) / G;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
         // ---- row pass ----
-        {
-            const int g = lane / H, r = lane % H;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_ROW; round++) {
+            const int t = round * 64 + lane, g = t / H, r = t % H;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu && r < HIN) {
+            if (tu < n_tu && r < HIN) {
                 const svthip_itxfm_desc d = desc[tu];
                 const int kr = kHtx[d.tx_type & 15];
                 const int32_t* in = coeff + d.coeff_offset + r * WIN;
@@ -81,10 +84,11 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- column pass ----
-        {
-            const int g = lane / W, c = lane % W;
+#pragma unroll 1
+        for (int round = 0; round < ROUNDS_COL; round++) {
+            const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
-            if (g < G && tu < n_tu) {
+            if (tu < n_tu) {
                 const svthip_itxfm_desc d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const int32_t* col = tile + g * (H * P) + (kr == 2 ? W - 1 - c : c);
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
 template <int WL, int HL, typename PIX>
 hipError_t launch_one(const int32_t* coeff, const svthip_itxfm_desc* desc, uint32_t n_tu, int bd, PIX* recon, hipStream_t s)
 {
-    constexpr int W = 1 << WL, H = 1 << HL, MAXD = W > H ? W : H, G = 64 / MAXD;
+    constexpr int W = 1 << WL, H = 1 << HL, MIND = W < H ? W : H, G = 64 / MIND;
     constexpr size_t lds = (size_t)4 * G * H * (W + 1) * sizeof(int32_t);
     const uint32_t groups = (n_tu + G - 1) / G;
     uint32_t blocks = (groups + 3) / 4;
