@@ -126,30 +126,58 @@ __global__ void __launch_bounds__(256) inv_txfm2d_add_kernel(const int32_t* __re
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // prediction + residual -> clip, 4 horizontally consecutive 8-bit pixels per lane (one dword load / store instead of
             // four byte loads / stores per lane); TUs whose rows are not 4-byte aligned take the byte path
-            for (int g = 0; g < G; g++) {
-                const uint32_t tu = grp * G + g;  // uniform
-                if (tu >= n_tu) break;
-                const svthip_itxfm_desc d = desc[tu];
-                uint8_t* base = reinterpret_cast<uint8_t*>(recon) + d.recon_offset;
-                const int stride = d.recon_stride;
-                const int32_t* tg = tile + g * (H * P);
-                if ((((uintptr_t)base | (uintptr_t)stride) & 3u) == 0) {
+            if constexpr (W * H / 4 < 64) {
+                // TUs smaller than one pass of the wave (16x4: 16 dwords): all TUs of the group in one flattened loop
+                constexpr int NQ = W * H / 4;
 #pragma unroll 2
-                    for (int q = lane; q < W * H / 4; q += 64) {
-                        const int r = (4 * q) / W, c = (4 * q) % W;
-                        uint32_t* p = reinterpret_cast<uint32_t*>(base + r * stride + c);
+                for (int i = lane; i < G * NQ; i += 64) {
+                    const int g = i / NQ, q = i - g * NQ;
+                    const uint32_t tu = grp * G + g;
+                    if (tu >= n_tu) continue;
+                    const svthip_itxfm_desc d = desc[tu];
+                    uint8_t* base = reinterpret_cast<uint8_t*>(recon) + d.recon_offset;
+                    const int stride = d.recon_stride;
+                    const int r = (4 * q) / W, c = (4 * q) % W;
+                    const int32_t* t4 = tile + g * (H * P) + r * P + c;
+                    uint8_t* p8 = base + r * stride + c;
+                    if ((((uintptr_t)base | (uintptr_t)stride) & 3u) == 0) {
+                        uint32_t* p = reinterpret_cast<uint32_t*>(p8);
                         const uint32_t pv = *p;
-                        const int32_t* t4 = tg + r * P + c;
                         uint32_t o = 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) o |= (uint32_t)min(max((int32_t)((pv >> (8 * k)) & 255u) + t4[k], 0), 255) << (8 * k);
                         *p = o;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) p8[k] = (uint8_t)min(max((int32_t)p8[k] + t4[k], 0), 255);
                     }
-                } else {
-                    for (int q = lane; q < W * H; q += 64) {
-                        const int r = q / W, c = q % W;
-                        uint8_t* p = base + r * stride + c;
-                        *p = (uint8_t)min(max((int32_t)*p + tg[r * P + c], 0), 255);
+                }
+            } else {
+                for (int g = 0; g < G; g++) {
+                    const uint32_t tu = grp * G + g;  // uniform
+                    if (tu >= n_tu) break;
+                    const svthip_itxfm_desc d = desc[tu];
+                    uint8_t* base = reinterpret_cast<uint8_t*>(recon) + d.recon_offset;
+                    const int stride = d.recon_stride;
+                    const int32_t* tg = tile + g * (H * P);
+                    if ((((uintptr_t)base | (uintptr_t)stride) & 3u) == 0) {
+#pragma unroll 2
+                        for (int q = lane; q < W * H / 4; q += 64) {
+                            const int r = (4 * q) / W, c = (4 * q) % W;
+                            uint32_t* p = reinterpret_cast<uint32_t*>(base + r * stride + c);
+                            const uint32_t pv = *p;
+                            const int32_t* t4 = tg + r * P + c;
+                            uint32_t o = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) o |= (uint32_t)min(max((int32_t)((pv >> (8 * k)) & 255u) + t4[k], 0), 255) << (8 * k);
+                            *p = o;
+                        }
+                    } else {
+                        for (int q = lane; q < W * H; q += 64) {
+                            const int r = q / W, c = q % W;
+                            uint8_t* p = base + r * stride + c;
+                            *p = (uint8_t)min(max((int32_t)*p + tg[r * P + c], 0), 255);
+                        }
                     }
                 }
             }
