@@ -7,10 +7,15 @@
 // Unaligned 4-byte read as two ALIGNED dword loads + v_alignbyte.  A single misaligned global_load_dword is
 // legal on gfx950 but was measured ~10x slower here (the 64 lanes of a wave are split into per-lane requests);
 // aligned neighbours coalesce into full-rate requests.
+// The aligned address is rebuilt from an integer; the pointer type carries the GLOBAL address space explicitly, otherwise the
+// integer-to-pointer cast yields a generic pointer and every load becomes a flat_load (which also ties the loads to the LDS
+// counter).  Everything these helpers read lives in the picture pool.
+typedef const __attribute__((address_space(1))) uint32_t gmem_u32;
+
 __device__ __forceinline__ uint32_t ldu32(const uint8_t* p)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    gmem_u32* q = (gmem_u32*)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3u);
     const uint32_t lo = q[0];
     const uint32_t hi = sh ? q[1] : 0u;
@@ -21,7 +26,7 @@ __device__ __forceinline__ uint32_t ldu32(const uint8_t* p)
 __device__ __forceinline__ uint32_t ldu32_nb(const uint8_t* p)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    gmem_u32* q = (gmem_u32*)(a & ~(uintptr_t)3);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u));
 }
 
@@ -174,7 +179,7 @@ __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t 
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int rr = min(r + k * G, wrows - 1) - r;   // >= 0 whenever this lane stores anything
-                v[k] = ldu32_nb(p + (ptrdiff_t)rr * (ptrdiff_t)ref_stride_raw);
+                v[k] = ldu32_nb(p + (ptrdiff_t)(rr * (int)ref_stride_raw));  // |rr| < 2^10, stride < 2^16: a 32-bit product
             }
 #pragma unroll
             for (int k = 0; k < 8; k++)

@@ -432,13 +432,13 @@ __global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict
         const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
         const uint32_t shf = (uint32_t)(a0 & 3u);
-        const uint32_t* base4 = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+        const __attribute__((address_space(1))) uint32_t* base4 = (const __attribute__((address_space(1))) uint32_t*)(a0 & ~(uintptr_t)3);  // global, not generic
         const int ndw = pitch >> 2, rstride4 = ref_stride >> 2;
         const int total = wrows * ndw;
         const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;
         for (int i = tid; i < total; i += 256) {
             const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
-            const uint32_t* p = base4 + (size_t)r * rstride4 + c;
+            const __attribute__((address_space(1))) uint32_t* p = base4 + (size_t)r * rstride4 + c;
             reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
         }
     }
@@ -537,13 +537,13 @@ __device__ void stage_window(lds_u8* wbuf, int pitch, int wrows, const uint8_t* 
     const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
     const uint32_t shf = (uint32_t)(a0 & 3u);
-    const uint32_t* base4 = reinterpret_cast<const uint32_t*>(a0 & ~(uintptr_t)3);
+    const __attribute__((address_space(1))) uint32_t* base4 = (const __attribute__((address_space(1))) uint32_t*)(a0 & ~(uintptr_t)3);  // global, not generic
     const int ndw = pitch >> 2, rstride4 = ref_stride >> 2;
     const int total = wrows * ndw;
     const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;
     for (int i = tid; i < total; i += nthreads) {
         const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
-        const uint32_t* p = base4 + (size_t)r * rstride4 + c;
+        const __attribute__((address_space(1))) uint32_t* p = base4 + (size_t)r * rstride4 + c;
         reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
     }
 }
