@@ -191,7 +191,9 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             t = json.load(f)["svthip::fullpel85_kernel"]
-        traffic = round((t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0)
+        # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM counters;
+        # confirmed on the transform kernels, where 2 x FETCH_SIZE matches the algorithmic bytes: profiles/r01_pmc_traffic_tq.json)
+        traffic = round((2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0)
     except (OSError, KeyError, ValueError):
         pass
 
@@ -220,9 +222,10 @@ def main():
                        "search_area": [SEARCH_W, SEARCH_H], "sharding": "pictures across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "traffic_note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB x 1024 from a separate rocprofv3 --pmc run "
-                                         "(profiles/r01_pmc_traffic.json); 4-byte-per-lane loads, for which the gfx950 FETCH_SIZE "
-                                         "scale is uncalibrated (x1..x2); algorithmic bytes per launch = 20905 x blocks",
+                         "traffic_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 from separate rocprofv3 --pmc passes "
+                                         "(profiles/r01_pmc_traffic.json; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950); "
+                                         "algorithmic bytes per launch = 20905 x blocks; the excess is 64/128-byte line granularity on "
+                                         "unaligned 127-byte window rows, irrelevant at 3 % of the HBM peak (VALU-bound)",
                          "kernel": "fullpel85_kernel", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_block": ALGO_BYTES_PER_BLOCK,
                          "note": "search is ~400 abs-diff per compulsory byte: VALU-bound by construction (SURVEY 8d); see valu",
