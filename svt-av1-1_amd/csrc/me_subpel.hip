@@ -581,18 +581,19 @@ constexpr PuTab make_pu_tab()
 }
 __device__ constexpr PuTab kPu = make_pu_tab();
 
-// Five wave roles, two shape classes each (a horizontal class and its transpose: equal pixel area per role):
-//   0: 64x32 | 32x64   1: 64x16 | 16x64   2: 32x16 | 16x32   3: 32x8 | 8x32   4: 16x8 | 8x16
-// with 64 / 64 / 32 / 16 / 8 lanes per PU.  Tile memory per role = the larger of its two classes times the PUs per pass.
+// Five wave roles, two shape classes each (equal pixel area per role).  Small PUs carry more interpolation halo per pixel, so
+// each role pairs a small-PU class with a large-PU class (tile samples per role: 36 k .. 41 k; class with its transpose: 30 k .. 50 k):
+//   0: 16x8 | 32x64   1: 8x16 | 64x32   2: 32x8 | 16x64   3: 8x32 | 64x16   4: 32x16 | 16x32
+// with 8 / 64, 8 / 64, 16 / 64, 16 / 64, 32 / 32 lanes per PU.  Tile memory per role = the larger of its two classes' passes.
 constexpr int kNsqRoles = 5;
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int kNsqTile[kNsqRoles] = {cmax(Tiles<64, 32>::bytes, Tiles<32, 64>::bytes), cmax(Tiles<64, 16>::bytes, Tiles<16, 64>::bytes),
-                                     2 * cmax(Tiles<32, 16>::bytes, Tiles<16, 32>::bytes), 4 * cmax(Tiles<32, 8>::bytes, Tiles<8, 32>::bytes),
-                                     8 * cmax(Tiles<16, 8>::bytes, Tiles<8, 16>::bytes)};
+constexpr int kNsqTile[kNsqRoles] = {cmax(8 * Tiles<16, 8>::bytes, Tiles<32, 64>::bytes), cmax(8 * Tiles<8, 16>::bytes, Tiles<64, 32>::bytes),
+                                     cmax(4 * Tiles<32, 8>::bytes, Tiles<16, 64>::bytes), cmax(4 * Tiles<8, 32>::bytes, Tiles<64, 16>::bytes),
+                                     2 * cmax(Tiles<32, 16>::bytes, Tiles<16, 32>::bytes)};
 __device__ constexpr int kNsqTileOff[kNsqRoles + 1] = {0, kNsqTile[0], kNsqTile[0] + kNsqTile[1], kNsqTile[0] + kNsqTile[1] + kNsqTile[2],
                                             kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3],
                                             (kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3] + kNsqTile[4] + 15) & ~15};
-__device__ constexpr int kNsqPredOff[kNsqRoles + 1] = {0, 2048, 3072, 4096, 5120, 6144};  // list-0 predictions: PUs per pass x PW x PH bytes
+__device__ constexpr int kNsqPredOff[kNsqRoles + 1] = {0, 2048, 4096, 5120, 6144, 7168};  // list-0 predictions: PUs per pass x PW x PH bytes
 
 // sub-pel refinement of the `count` PUs of one shape class starting at raster PU index `base`, 64 / LPP of them per pass
 template <int PW, int PH, int LPP>
@@ -789,20 +790,20 @@ __global__ void __launch_bounds__(320) subpel_nsq_kernel(const uint8_t* __restri
     uint32_t* pred = pred_out ? pred_out + (size_t)blockIdx.x * 14 * 1024 : nullptr;
 #define SLOT(k) (pred ? pred + (k) * 1024 : nullptr)
     if (role == 0) {
-        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2, SLOT(4));
+        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32, SLOT(6));
         refine_class<32, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 127, 2, SLOT(7));
     } else if (role == 1) {
-        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4, SLOT(12));
-        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4, SLOT(13));
+        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32, SLOT(9));
+        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2, SLOT(4));
     } else if (role == 2) {
+        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16, SLOT(10));
+        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4, SLOT(13));
+    } else if (role == 3) {
+        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16, SLOT(11));
+        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4, SLOT(12));
+    } else {
         refine_class<32, 16, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 87, 8, SLOT(5));
         refine_class<16, 32, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 129, 8, SLOT(8));
-    } else if (role == 3) {
-        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16, SLOT(10));
-        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16, SLOT(11));
-    } else {
-        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32, SLOT(6));
-        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32, SLOT(9));
     }
 #undef SLOT
 }
@@ -853,20 +854,20 @@ __global__ void __launch_bounds__(320) bipred_nsq_pack_kernel(const uint8_t* __r
         lds_u8* tiles = tile_base + kNsqTileOff[role];
         lds_u8* pred = pred_base + kNsqPredOff[role];
         if (role == 0) {
-            bipred_class<64, 32, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 85, 2);
+            bipred_class<16, 8, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 95, 32);
             bipred_class<32, 64, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 127, 2);
         } else if (role == 1) {
-            bipred_class<64, 16, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 201, 4);
-            bipred_class<16, 64, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 205, 4);
+            bipred_class<8, 16, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 137, 32);
+            bipred_class<64, 32, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 85, 2);
         } else if (role == 2) {
+            bipred_class<32, 8, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 169, 16);
+            bipred_class<16, 64, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 205, 4);
+        } else if (role == 3) {
+            bipred_class<8, 32, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 185, 16);
+            bipred_class<64, 16, 64>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 201, 4);
+        } else {
             bipred_class<32, 16, 32>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 87, 8);
             bipred_class<16, 32, 32>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 129, 8);
-        } else if (role == 3) {
-            bipred_class<32, 8, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 169, 16);
-            bipred_class<8, 32, 16>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 185, 16);
-        } else {
-            bipred_class<16, 8, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 95, 32);
-            bipred_class<8, 16, 8>(src_lds, win0, win1, tiles, pred, m0, xo0, yo0, m1, xo1, yo1, lane, bisad, 137, 32);
         }
         __syncthreads();
     }
