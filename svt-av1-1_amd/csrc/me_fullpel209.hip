@@ -12,7 +12,7 @@ namespace fp209 {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 2) fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+__global__ void __launch_bounds__(256, 3) fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                             const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                                             const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
                                                             uint32_t* __restrict__ out_mv)
