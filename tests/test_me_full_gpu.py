@@ -106,6 +106,23 @@ def test_motion_estimate_picture_1080p_b_picture(hip_ctx, oracle):
     compare_results(res_d[sample], res_o)
 
 
+def test_motion_estimate209_1080p_b_picture(hip_ctx, oracle):
+    """Full-size B picture through the 209-PU chain; size-independent properties over all 510 SBs and a sample against the oracle."""
+    pytest.importorskip("torch")
+    pics = _pics(1920, 1080, "synth")
+    P = svtav1_hip.default_me_params(1920, 1080, 3, 1)
+    res_d, ls, lm = device_me_picture(hip_ctx, pics, P, True, True, 0, n_pu=209)
+    assert (res_d["totalMeCandidateIndex"] == 3).all()
+    d = res_d["distortion"]
+    assert (d[:, :, 0] <= d[:, :, 1]).all() and (d[:, :, 1] <= d[:, :, 2]).all()
+    assert (np.sort(res_d["direction"], axis=2) == np.arange(3)).all()  # each of L0 / L1 / bi-pred exactly once
+    sample = np.sort(np.random.default_rng(23).choice(510, 8, replace=False))
+    res_o, per = oracle_me_picture(oracle, pics, P, True, True, 0, sb_subset=sample, n_pu=209)
+    for l in per:
+        assert np.array_equal(ls[l][sample], per[l][1]) and np.array_equal(lm[l][sample], per[l][2])
+    compare_results(res_d[sample], res_o)
+
+
 def test_batched_pictures_equal_single_picture_calls(hip_ctx):
     """svthip_motion_estimate_batch_dev over several B pictures == one svthip_motion_estimate_picture_dev per picture."""
     torch = pytest.importorskip("torch")
