@@ -99,8 +99,10 @@ ls "$S"/Lib/{C_DEFAULT,ASM_SSE2,ASM_SSSE3,ASM_SSE4_1,ASM_AVX2,Codec}/*.c | xargs
   'o="$OUT/obj_all/$(basename {} .c).o"; if [ ! -f "$o" ] || [ {} -nt "$o" ]; then gcc $CFLAGS $INC -c {} -o "$o"; fi'
 gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_me_lcu_driver.c" -o "$OUT/obj/ref_me_lcu_driver.o"
 gcc -O2 -std=gnu99 -Wall -fPIC -ffunction-sections -c "$HERE/ref_fullpel209_driver.c" -o "$OUT/obj/ref_fullpel209_driver.o"
-printf '{ global: ref_me_lcu_run; ref_interp_region; ref_fullpel_search_209pu; local: *; };\n' > "$OUT/obj/me.map"
-gcc -shared -o "$OUT/libsvtref_me.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_me_lcu_driver.o" "$OUT/obj/ref_fullpel209_driver.o" \
+# leaf kernels of the sub-pel refinement called through the reference's own function-pointer tables (headers where they lie)
+gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_subpel_leaf_driver.c" -o "$OUT/obj/ref_subpel_leaf_driver.o"
+printf '{ global: ref_me_lcu_run; ref_interp_region; ref_fullpel_search_209pu; ref_halfpel_ssd_leaf; ref_halfpel_sad_leaf; ref_quarterpel_ssd_leaf; ref_quarterpel_sad_leaf; local: *; };\n' > "$OUT/obj/me.map"
+gcc -shared -o "$OUT/libsvtref_me.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_me_lcu_driver.o" "$OUT/obj/ref_fullpel209_driver.o" "$OUT/obj/ref_subpel_leaf_driver.o" \
     -Wl,--gc-sections -Wl,--version-script="$OUT/obj/me.map" -lm -lpthread
 echo "built $OUT/libsvtref_me.so (unresolved by design: $(nm -D "$OUT/libsvtref_me.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"
 

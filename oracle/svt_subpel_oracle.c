@@ -10,7 +10,10 @@
  * PINNING STATUS.  The leaf arithmetic is pinned against the reference's own kernels in oracle/_ref
  * (AvcStyleLumaInterpolationFilter{Horizontal,Vertical}_SSSE3_INTRIN, SpatialFullDistortionKernel*_SSSE3_INTRIN,
  * CombinedAveragingSAD) and the plane geometry against the reference's InterpolateSearchRegionAVC
- * (tests/test_subpel_vs_ref.py).  The per-PU refinement CONTROL FLOW (PU_HalfPelRefinement and the quarter-pel
+ * (tests/test_subpel_vs_ref.py).  The leaf DISPATCH is pinned per (width, height): orc_halfpel_ssd_dispatched /
+ * orc_halfpel_sad_dispatched / orc_quarterpel_*_dispatched below restate which table entry PU_HalfPelRefinement /
+ * PU_QuarterPelRefinementOnTheFly index for a PU size, and tests/test_subpel_vs_ref.py compares them with the reference's
+ * own function-pointer tables (oracle/ref_subpel_leaf_driver.c) for every (w,h) pair HalfPelSearch_LCU passes.  The per-PU refinement CONTROL FLOW (PU_HalfPelRefinement and the quarter-pel
  * functions) is restated from the source text only: the reference's sub-pel path calls Log2f_SSE2, which exists
  * only in a NASM file this image cannot assemble, so it cannot be executed here -- "parity unpinned" for that
  * control flow (DESIGN.md "oracle").
@@ -75,6 +78,63 @@ uint32_t orc_ssd_wrapped(const uint8_t *src, uint32_t src_stride, const uint8_t 
     return s;
 }
 
+/* Rows the half-pel stage's SSD covers for a w x h PU.  PU_HalfPelRefinement picks the SSD leaf by WIDTH only:
+ * SpatialFullDistortionKernel_funcPtrArray[asm_type][Log2f(pu_width) - 2] (Codec/EbMotionEstimation.c:1912, :1929, :1964 ...;
+ * table Codec/EbPictureOperators.h:532-559).  Width 8 selects SpatialFullDistortionKernel8x8_SSSE3_INTRIN, which always
+ * runs 8 rows and ignores areaHeight (ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c:534-571), so the 8x16 and 8x32 PUs
+ * of the 209-PU mode are compared on their top 8 rows only; widths 16/32/64 select the 16MxN kernel (all rows). */
+static inline int halfpel_ssd_rows(int w, int h) { return w == 8 ? 8 : h; }
+
+/* the half-pel stage's SSD exactly as PU_HalfPelRefinement dispatches it for a (w,h) PU */
+uint32_t orc_halfpel_ssd_dispatched(const uint8_t *src, uint32_t src_stride, const uint8_t *rec, uint32_t rec_stride, uint32_t w, uint32_t h)
+{
+    return orc_ssd_wrapped(src, src_stride, rec, rec_stride, w, (uint32_t)halfpel_ssd_rows((int)w, (int)h));
+}
+
+/* the SAD stored on improvement: NxMSadKernel_funcPtrArray[asm_type][pu_width >> 3](.., pu_height, pu_width), all rows
+ * (:1943; table Codec/EbComputeSAD.h:126-152: FastLoop_NxMSadKernel for every width in the ASM_NON_AVX2 row) */
+uint32_t orc_halfpel_sad_dispatched(const uint8_t *src, uint32_t src_stride, const uint8_t *rec, uint32_t rec_stride, uint32_t w, uint32_t h)
+{
+    uint32_t s = 0;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const int d = (int)src[y * src_stride + x] - (int)rec[y * rec_stride + x];
+            s += (uint32_t)(d < 0 ? -d : d);
+        }
+    return s;
+}
+
+/* quarter-pel stage: CombinedAveragingSSD (true SSD, all rows, :2792-2817, call :2914) and the stored
+ * NxMSadAveragingKernel_funcPtrArray[asm_type][pu_width >> 3] = CombinedAveragingSAD (all rows, :2929) */
+uint32_t orc_quarterpel_ssd_dispatched(const uint8_t *src, uint32_t src_stride, const uint8_t *r1, uint32_t r1_stride, const uint8_t *r2,
+                                       uint32_t r2_stride, uint32_t w, uint32_t h)
+{
+    uint32_t s = 0;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const int e = (int)src[y * src_stride + x] - ((r1[y * r1_stride + x] + r2[y * r2_stride + x] + 1) >> 1);
+            s += (uint32_t)(e * e);
+        }
+    return s;
+}
+
+uint32_t orc_quarterpel_sad_dispatched(const uint8_t *src, uint32_t src_stride, const uint8_t *r1, uint32_t r1_stride, const uint8_t *r2,
+                                       uint32_t r2_stride, uint32_t w, uint32_t h)
+{
+    uint32_t s = 0;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const int e = (int)src[y * src_stride + x] - ((r1[y * r1_stride + x] + r2[y * r2_stride + x] + 1) >> 1);
+            s += (uint32_t)(e < 0 ? -e : e);
+        }
+    return s;
+}
+
+/* 0 = every half-pel SSD over all rows (the round-1 restatement, kept ONLY so that tests can show the 8-wide classes change);
+ * 1 = as the reference dispatches it (default) */
+static int g_halfpel_dispatch_exact = 1;
+void orc_set_halfpel_dispatch_exact(int on) { g_halfpel_dispatch_exact = on; }
+
 #define DIR_TL 0
 #define DIR_T 1
 #define DIR_TR 2
@@ -94,8 +154,9 @@ static void pu_half_pel(const uint8_t *src, int src_stride, const RefView *r, in
     const int16_t x_mv = (int16_t)(*best_mv & 0xffff), y_mv = (int16_t)(*best_mv >> 16);
     const int xs = (x_mv >> 2) - xo, ys = (y_mv >> 2) - yo;
     const uint8_t *s = src + py * src_stride + px;
+    const int hs = g_halfpel_dispatch_exact ? halfpel_ssd_rows(w, h) : h; /* rows the width-keyed SSD leaf covers */
     uint32_t ssd = 0;
-    for (int y = 0; y < h; y++)
+    for (int y = 0; y < hs; y++)
         for (int x = 0; x < w; x++) ssd += wrap_sq(s[y * src_stride + x], A_(r, xs + px + x, ys + py + y));
     *best_ssd = ssd; /* :1912 */
     uint64_t dist[8];
@@ -105,7 +166,7 @@ static void pu_half_pel(const uint8_t *src, int src_stride, const RefView *r, in
             for (int x = 0; x < w; x++) {
                 const int p = sample(r, kHalf[k][0], xs + px + x + kHalf[k][1], ys + py + y + kHalf[k][2]);
                 const int sv = s[y * src_stride + x];
-                d += wrap_sq(sv, p);
+                if (y < hs) d += wrap_sq(sv, p);
                 sad += (uint32_t)(sv > p ? sv - p : p - sv);
             }
         dist[k] = d;

@@ -249,10 +249,14 @@ __device__ void half_pel_pu(const lds_u8* src, const Win& win, const T& t, int p
                                __builtin_amdgcn_alignbyte(h1, h0, 2), __builtin_amdgcn_alignbyte(h3, h2, 2),
                                __builtin_amdgcn_alignbyte(j1, j0, 2), __builtin_amdgcn_alignbyte(j1, j0, 3),
                                __builtin_amdgcn_alignbyte(j3, j2, 3), __builtin_amdgcn_alignbyte(j3, j2, 2)};
-        ssd[8] = wssd4(s4, lds_u32_at(win.p + (by + y + kMargin) * win.pitch + bx + x + kMargin), ssd[8]);
+        // The reference picks the SSD leaf by WIDTH only (SpatialFullDistortionKernel_funcPtrArray[asm][Log2f(pu_width) - 2], :1912) and
+        // the width-8 leaf always runs 8 rows whatever pu_height is (ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c:534-571): 8x16 and
+        // 8x32 PUs are compared on their top 8 rows.  The stored SAD (NxMSadKernel, :1943) covers every row.
+        const bool in_ssd = (PW != 8) || (y < 8);
+        if (in_ssd) ssd[8] = wssd4(s4, lds_u32_at(win.p + (by + y + kMargin) * win.pitch + bx + x + kMargin), ssd[8]);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            ssd[k] = wssd4(s4, c[k], ssd[k]);
+            if (in_ssd) ssd[k] = wssd4(s4, c[k], ssd[k]);
             sad[k] = __builtin_amdgcn_sad_u8(s4, c[k], sad[k]);
         }
     }

@@ -117,3 +117,35 @@ def test_subpel209_matches_oracle(hip_ctx, oracle, kind, search):
     assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}, PUs {sorted(set(bad[:, 1].tolist()))[:24]}"
     if kind == "smooth":
         assert (m_o[:, 85:] != m0[:, 85:]).any()  # the refinement moved some rectangular PUs
+
+
+def test_subpel209_8_wide_rectangles_follow_the_8_row_ssd(hip_ctx, oracle):
+    """The reference dispatches the half-pel SSD by width only and its width-8 leaf runs 8 rows (8x16 / 8x32 PUs are compared on
+    their top 8 rows; tests/test_subpel_vs_ref.py pins that against the reference's own tables).  The device result must equal the
+    oracle with that dispatch AND differ from the all-rows restatement in the 8-wide rectangular classes -- otherwise this test
+    could not tell the two metrics apart."""
+    torch = pytest.importorskip("torch")
+    cur, ref = _pictures(256, 192, "synth")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    s0, m0 = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    s_o, m_o = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    oracle.lib.orc_set_halfpel_dispatch_exact(0)
+    try:
+        s_all, m_all = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    finally:
+        oracle.lib.orc_set_halfpel_dispatch_exact(1)
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(cur.full).to(dev); d_ref = torch.from_numpy(ref.full).to(dev); d_desc = torch.from_numpy(desc).to(dev)
+    d_sad = torch.from_numpy(s0.view(np.int32).copy()).to(dev); d_mv = torch.from_numpy(m0.view(np.int32).copy()).to(dev)
+    torch.cuda.synchronize()
+    hip_ctx.subpel_refine209_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), desc.shape[0],
+                                 64, 64, d_sad.data_ptr(), d_mv.data_ptr())
+    hip_ctx.synchronize()
+    s_h, m_h = d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
+    assert np.array_equal(s_h, s_o) and np.array_equal(m_h, m_o)
+    g = oracle.pu_geometry209()
+    narrow = np.zeros(209, bool)
+    narrow[[int(g[pu, 4]) for pu in range(209) if g[pu, 0] == 8 and g[pu, 1] > 8]] = True
+    assert narrow.sum() == 48
+    differs = (m_h != m_all) | (s_h != s_all)
+    assert differs[:, narrow].any() and not differs[:, ~narrow].any()

@@ -131,3 +131,96 @@ def test_subpel_finds_true_half_pel_shift(oracle):
             x = int(np.int16(m1[i, pu] & 0xffff)); y = int(np.int16(m1[i, pu] >> 16))
             assert (x, y) == (-2, 0), f"SB {i} PU {pu}: MV ({x},{y}) instead of the half-pel position (-2,0)"
             assert ssd[i, pu] == 0
+
+
+# every (width, height) pair HalfPelSearch_LCU / QuarterPelSearch_LCU pass to the PU refinement functions
+# (Codec/EbMotionEstimation.c:2278-2786, :3369-4114): the 4 square and 10 rectangular shape classes of the 209-PU mode
+PU_SHAPES = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 16), (16, 8), (32, 64), (16, 32), (8, 16), (32, 8), (8, 32),
+             (64, 16), (16, 64)]
+
+
+def _leaf_fn(refme, name, n_ptr):
+    f = getattr(refme.lib, name)
+    f.restype = C.c_uint32
+    return f
+
+
+@pytest.mark.parametrize("asm_type", [0, 1])
+@pytest.mark.parametrize("shape", PU_SHAPES)
+def test_half_pel_leaf_dispatch_per_shape(oracle, refme, shape, asm_type):
+    """The half-pel stage's two metrics as the reference DISPATCHES them for a (w,h) PU: the SSD leaf is picked by width
+    only -- SpatialFullDistortionKernel_funcPtrArray[asm][Log2f(pu_width) - 2] -- and the width-8 leaf always runs 8 rows,
+    so 8x16 / 8x32 PUs are compared on their top 8 rows; the stored SAD (NxMSadKernel_funcPtrArray[asm][pu_width >> 3])
+    covers every row.  The table index is computed here as floor(log2(w)) - 2 (what Log2f means; the NASM Log2f_SSE2
+    itself cannot be assembled in this image and no stand-in is linked)."""
+    w, h = shape
+    ssd_ref = refme.lib.ref_halfpel_ssd_leaf; ssd_ref.restype = C.c_uint32
+    sad_ref = refme.lib.ref_halfpel_sad_leaf; sad_ref.restype = C.c_uint32
+    ssd_orc = oracle.lib.orc_halfpel_ssd_dispatched; ssd_orc.restype = C.c_uint32
+    sad_orc = oracle.lib.orc_halfpel_sad_dispatched; sad_orc.restype = C.c_uint32
+    for f in (ssd_ref, sad_ref):
+        f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    for f in (ssd_orc, sad_orc):
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    ssd_index = int(np.log2(w)) - 2
+    rng = np.random.default_rng(100 * w + h)
+    ss, rs = 200, 1350  # source stride of a padded plane / interpolated_stride
+    for trial in range(6):
+        src = rng.integers(0, 256, (h, ss), dtype=np.uint8)
+        rec = rng.integers(0, 256, (h, rs), dtype=np.uint8)
+        if trial == 0:
+            src[:] = 255; rec[:] = 0
+        if trial == 1:
+            src[:] = 200; rec[:] = 72
+        want_ssd = ssd_ref(asm_type, ssd_index, src.ctypes.data, ss, rec.ctypes.data, rs, w, h)
+        want_sad = sad_ref(asm_type, w >> 3, src.ctypes.data, ss, rec.ctypes.data, rs, w, h)
+        assert ssd_orc(src.ctypes.data, ss, rec.ctypes.data, rs, w, h) == want_ssd, f"SSD as dispatched for {w}x{h}"
+        assert sad_orc(src.ctypes.data, ss, rec.ctypes.data, rs, w, h) == want_sad, f"SAD as dispatched for {w}x{h}"
+        if w == 8 and h > 8 and trial >= 2:
+            full = oracle.ssd_wrapped(np.ascontiguousarray(src[:, :w]), np.ascontiguousarray(rec[:, :w]))
+            assert full != want_ssd, "the 8-row leaf and the full-height sum must differ on random data"
+
+
+@pytest.mark.parametrize("asm_type", [0, 1])
+@pytest.mark.parametrize("shape", PU_SHAPES)
+def test_quarter_pel_leaf_dispatch_per_shape(oracle, refme, shape, asm_type):
+    """Quarter-pel stage: CombinedAveragingSSD (true SSD) for the comparison and NxMSadAveragingKernel_funcPtrArray[asm][w >> 3]
+    for the stored SAD, both over every row of the PU, source read at stride 64 (sb_buffer)."""
+    w, h = shape
+    ssd_ref = refme.lib.ref_quarterpel_ssd_leaf; ssd_ref.restype = C.c_uint32
+    ssd_ref.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    sad_ref = refme.lib.ref_quarterpel_sad_leaf; sad_ref.restype = C.c_uint32
+    sad_ref.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    ssd_orc = oracle.lib.orc_quarterpel_ssd_dispatched; ssd_orc.restype = C.c_uint32
+    sad_orc = oracle.lib.orc_quarterpel_sad_dispatched; sad_orc.restype = C.c_uint32
+    for f in (ssd_orc, sad_orc):
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(7 * w + h)
+    for trial in range(4):
+        src = rng.integers(0, 256, (h, 64), dtype=np.uint8)
+        r1 = rng.integers(0, 256, (h, 1350), dtype=np.uint8)
+        r2 = rng.integers(0, 256, (h, 200), dtype=np.uint8)
+        a = (src.ctypes.data, 64, r1.ctypes.data, 1350, r2.ctypes.data, 200, w, h)
+        assert ssd_orc(*a) == ssd_ref(*a)
+        assert sad_orc(*a) == sad_ref(asm_type, w >> 3, *a)
+
+
+def test_8_wide_rectangles_use_the_8_row_metric(oracle):
+    """The 209-PU refinement with the reference's dispatch differs from the all-rows restatement (round 1) in the 8x16 and
+    8x32 classes and ONLY there."""
+    cur, ref, desc = _setup("synth")  # textured pictures with noise: no exact full-pel match, sub-pel candidates do win
+    s0, m0 = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    s_ref, m_ref = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    oracle.lib.orc_set_halfpel_dispatch_exact(0)
+    try:
+        s_all, m_all = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    finally:
+        oracle.lib.orc_set_halfpel_dispatch_exact(1)
+    g = oracle.pu_geometry209()
+    narrow = np.zeros(209, bool)
+    for pu in range(209):
+        if g[pu, 0] == 8 and g[pu, 1] > 8:
+            narrow[g[pu, 4]] = True
+    diff = (m_ref != m_all) | (s_ref != s_all)
+    assert diff[:, narrow].any(), "the 8-row metric must change some 8x16 / 8x32 result on random pictures"
+    assert not diff[:, ~narrow].any(), "every other shape class is independent of the fix"
