@@ -414,6 +414,29 @@ int32_t svthip_motion_estimate209_batch_dev(svthip_ctx *ctx, const uint8_t *d_po
                                             const svthip_sb_origin *d_sb, uint32_t n_sb, svthip_me_cu_result *d_out,
                                             uint32_t *d_list_sad, uint32_t *d_list_mv, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Picture-analysis producers of the ME inputs, on the device.  The host uploads the padded full-resolution
+ * luma ONCE (only its width x height interior has to be valid); this call then
+ *   - replicates the picture edges into the 68-sample border of the full-resolution plane
+ *     (PadPictureToMultipleOfLcuDimensions -> generate_padding, Codec/EbPictureAnalysisProcess.c:4866-4880, Codec/EbMcp.c:173-215),
+ *   - writes the complete "quarter" plane (every 2nd sample / row, 32-sample border) when want_quarter != 0 and the complete
+ *     "sixteenth" plane (every 4th, 16-sample border) when want_sixteenth != 0
+ *     (DecimateInputPicture = Decimation2D + generate_padding, Codec/EbPictureAnalysisProcess.c:100-125, :4885-4936; the
+ *     reference gates them on enable_hme_level1_flag / enable_hme_level0_flag),
+ * for n_pics pictures of the pool in one launch.  pics: HOST array of descriptors (plane offsets / strides in d_pool); the
+ * decimated planes' strides must be at least width/2 + 64 resp. width/4 + 32.  Bit-identical to the reference's two-pass
+ * padding and its decimate-then-pad order (every output sample is the input sample at clamped coordinates). */
+int32_t svthip_pa_derive_planes_dev(svthip_ctx *ctx, uint8_t *d_pool, const svthip_pa_picture *pics, uint32_t n_pics,
+                                    int32_t want_quarter, int32_t want_sixteenth, void *stream);
+
+/* generate_padding (sample_bytes = 1, Codec/EbMcp.c:173-215) / generate_padding16_bit (sample_bytes = 2, :220-262) of one plane
+ * in place, as PadRefAndSetFlags applies them to a reconstructed reference picture (Codec/EbEncDecProcess.c:1135-1204).
+ * d_plane points at the first sample of the PADDED plane; stride, width, height, pad_width, pad_height are in SAMPLES
+ * (the reference's 16-bit variant takes bytes; this entry takes samples for both depths).  The width x height interior at
+ * (pad_width, pad_height) is read, the border is written. */
+int32_t svthip_pad_plane_dev(svthip_ctx *ctx, void *d_plane, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_width,
+                             uint32_t pad_height, uint32_t sample_bytes, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

@@ -175,6 +175,29 @@ class Oracle:
               s0.ctypes.data, m0.ctypes.data, None, None, 1, int(bipred_8x8), out.ctypes.data)
         return out
 
+    def generate_padding(self, plane, width, height, pad_w, pad_h):
+        """In place on a 2-D uint8 / uint16 array whose row length is the stride (samples)."""
+        f = self.lib.orc_generate_padding if plane.dtype == np.uint8 else self.lib.orc_generate_padding16
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        f(plane.ctypes.data, plane.shape[1], width, height, pad_w, pad_h)
+
+    def pa_derive_planes(self, luma, full_stride=None, quarter_stride=None, sixteenth_stride=None):
+        """luma [h,w] uint8 -> (full, quarter, sixteenth) padded planes as Picture Analysis leaves them."""
+        h, w = luma.shape
+        fs = full_stride or w + 136
+        qs = quarter_stride or (w >> 1) + 64
+        ss = sixteenth_stride or (w >> 2) + 32
+        full = np.full((h + 136, fs), 0xA5, np.uint8)
+        full[68:68 + h, 68:68 + w] = luma
+        quarter = np.full(((h >> 1) + 64, qs), 0x5A, np.uint8)
+        sixteenth = np.full(((h >> 2) + 32, ss), 0x3C, np.uint8)
+        f = self.lib.orc_pa_derive_planes
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        f(full.ctypes.data, fs, w, h, quarter.ctypes.data, qs, sixteenth.ctypes.data, ss)
+        return full, quarter, sixteenth
+
     def sad_loop(self, src, src_off, src_stride, ref, ref_off, ref_stride, height, width, ref_stride_raw, sw, sh):
         best = C.c_uint64(0)
         x = C.c_int16(-12345)

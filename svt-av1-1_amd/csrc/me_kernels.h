@@ -32,6 +32,13 @@ __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable 
                                   uint32_t l0_mv_stride, svthip_fullpel_desc* __restrict__ out_desc,
                                   int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
+// job table of one picture-analysis launch (pa_planes.hip), passed by value
+struct PaJobTable {
+    svthip_pa_picture pic[SVTHIP_HME_MAX_JOBS];
+};
+__global__ void pa_derive_planes_kernel(uint8_t* __restrict__ pool, PaJobTable jobs, int do_quarter, int do_sixteenth);
+hipError_t launch_pad_plane(void* plane, uint32_t stride, int width, int height, int pad_w, int pad_h, int sample_bytes, hipStream_t s);
+
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                 const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
                                 int disable_8x8, int pu_stride, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv,

@@ -631,6 +631,56 @@ int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size
     return SVTHIP_OK;
 }
 
+int32_t svthip_pa_derive_planes_dev(svthip_ctx* ctx, uint8_t* d_pool, const svthip_pa_picture* pics, uint32_t n_pics, int32_t want_quarter,
+                                    int32_t want_sixteenth, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (n_pics == 0) return SVTHIP_OK;
+    if (!d_pool || !pics) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t max_dw = 0;
+    for (uint32_t j = 0; j < n_pics; j++) {
+        const svthip_pa_picture& p = pics[j];
+        if ((p.width & 7) || (p.height & 7) || p.width == 0 || p.height == 0)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be non-zero multiples of 8%s (picture %d)", "", (int)j);
+        if (p.full_stride < (uint32_t)p.width + 136u || (p.full_stride & 3u) || (p.full_offset & 3))
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "full-resolution stride must be a multiple of 4 and >= width + 136%s (picture %d)", "", (int)j);
+        if (want_quarter && p.quarter_stride < (uint32_t)(p.width >> 1) + 64u)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "quarter stride must be >= width/2 + 64%s (picture %d)", "", (int)j);
+        if (want_sixteenth && p.sixteenth_stride < (uint32_t)(p.width >> 2) + 32u)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "sixteenth stride must be >= width/4 + 32%s (picture %d)", "", (int)j);
+        const uint32_t dw = ((uint32_t)p.width + 136u + 3u) / 4u * ((uint32_t)p.height + 136u);
+        if (dw > max_dw) max_dw = dw;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    for (uint32_t j0 = 0; j0 < n_pics; j0 += SVTHIP_HME_MAX_JOBS) {
+        const uint32_t nj = (n_pics - j0 < SVTHIP_HME_MAX_JOBS) ? n_pics - j0 : SVTHIP_HME_MAX_JOBS;
+        svthip::PaJobTable jt;
+        memset(&jt, 0, sizeof(jt));
+        for (uint32_t j = 0; j < nj; j++) jt.pic[j] = pics[j0 + j];
+        const uint32_t bx = (max_dw + 255u) / 256u;
+        hipLaunchKernelGGL(svthip::pa_derive_planes_kernel, dim3(bx < 1024u ? bx : 1024u, 3, nj), dim3(256), 0, s, d_pool, jt, (int)want_quarter,
+                           (int)want_sixteenth);
+        HIP_TRY(hipGetLastError());
+    }
+    return SVTHIP_OK;
+}
+
+int32_t svthip_pad_plane_dev(svthip_ctx* ctx, void* d_plane, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_width,
+                             uint32_t pad_height, uint32_t sample_bytes, void* stream)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (!d_plane) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "sample_bytes must be 1 or 2%s (got %d)", "", (int)sample_bytes);
+    if (width == 0 || height == 0 || stride < width + 2 * pad_width || width > 16384 || height > 16384 || pad_width > 1024 || pad_height > 1024)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "bad plane geometry%s (stride %d)", "", (int)stride);
+    if (sample_bytes == 2 && (reinterpret_cast<uintptr_t>(d_plane) & 1u)) return fail(SVTHIP_ERR_BAD_PARAMETER, "16-bit plane must be 2-byte aligned%s", "");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(svthip::launch_pad_plane(d_plane, stride, (int)width, (int)height, (int)pad_width, (int)pad_height, (int)sample_bytes, s));
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride,
                                           const uint8_t* d_ref_plane, uint32_t ref_stride,
                                           const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_search_area_width,

@@ -116,6 +116,10 @@ def lib() -> C.CDLL:
     L.svthip_encode_tu_batch_dev.restype = C.c_int32
     L.svthip_encode_tu_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                              C.c_uint32] + [C.c_void_p] * 9
+    L.svthip_pa_derive_planes_dev.restype = C.c_int32
+    L.svthip_pa_derive_planes_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]
+    L.svthip_pad_plane_dev.restype = C.c_int32
+    L.svthip_pad_plane_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -327,6 +331,21 @@ def _encode_tu_batch_dev(self, d_src, d_pred, d_recon, d_desc, n_tu, tx_width, t
 Context.encode_tu_batch_dev = _encode_tu_batch_dev
 
 
+def _pa_derive_planes_dev(self, d_pool, pics, want_quarter=True, want_sixteenth=True, stream=None):
+    """Pad the full-resolution planes and build the 1/4 and 1/16 planes of `pics` (PaPictureDesc list) inside the device pool."""
+    n = len(pics)
+    _check(lib().svthip_pa_derive_planes_dev(self._h, d_pool, (PaPictureDesc * n)(*pics), n, int(want_quarter), int(want_sixteenth), stream))
+
+
+def _pad_plane_dev(self, d_plane, stride, width, height, pad_w, pad_h, sample_bytes=1, stream=None):
+    """generate_padding / generate_padding16_bit of one device plane in place (all quantities in samples)."""
+    _check(lib().svthip_pad_plane_dev(self._h, d_plane, stride, width, height, pad_w, pad_h, sample_bytes, stream))
+
+
+Context.pa_derive_planes_dev = _pa_derive_planes_dev
+Context.pad_plane_dev = _pad_plane_dev
+
+
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:
     """Descriptors for every SB of a picture the way MotionEstimateLcu derives them
     (Codec/EbMotionEstimation.c:6667-6738): window centred on `centers[sb] = (x, y)` (default 0,0),
@@ -488,11 +507,8 @@ def sb_origins(width: int, height: int) -> np.ndarray:
 
 
 def shard_sb_rows(width: int, height: int, world: int, rank: int) -> np.ndarray:
-    """Contiguous SB-row partition of one picture across `world` ranks (1080p -> 17 rows -> 3/2/2/...):
-    returns the indices (into sb_origins(width, height)) of the SBs rank `rank` owns.  ME is open-loop, so shards need
-    no exchange: every rank holds the (read-only) planes and writes only its own rows of me_results."""
-    nx, ny = (width + 63) // 64, (height + 63) // 64
-    base, extra = divmod(ny, world)
-    first = rank * base + min(rank, extra)
-    count = base + (1 if rank < extra else 0)
-    return np.arange(first * nx, (first + count) * nx, dtype=np.int64)
+    """Contiguous SB-ROW partition of one picture across `world` ranks (1080p -> 17 rows -> 3/2/2/...): the indices
+    (into sb_origins(width, height)) of the SBs rank `rank` owns.  See svtav1_hip.sharded for the multi-GPU layer built on it."""
+    from .sharded import shard_sb_indices
+
+    return shard_sb_indices(width, height, world, rank, "row")

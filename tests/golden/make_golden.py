@@ -119,7 +119,43 @@ def transform_fixture():
     np.savez_compressed(os.path.join(HERE, "transforms.npz"), **out)
 
 
+def quant_tables_fixture():
+    """The reference's real quantiser rows and scan orders (oracle/ref_quant_tables_driver.c):
+    av1_build_quantizer for 8- and 10-bit video with the delta-q sets av1_set_quantizer produces (chroma -20 for inter, -10 for
+    intra slices, TUNE_CHROMA_OFFSET), in the ABI's row layout [256][3 planes][10]; av1_scan_orders[tx_size][tx_type] de-duplicated."""
+    import ctypes as C
+    me = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), mode=os.RTLD_LAZY)
+    out = {}
+    for bd in (8, 10):
+        for name, dq in (("inter", -20), ("intra", -10), ("flat", 0)):
+            rows = np.zeros((256, 3, 10), np.int16)
+            rc = me.ref_build_quantizer_rows(bd, 0, dq, dq, dq, dq, C.c_void_p(rows.ctypes.data))
+            assert rc == 0
+            out[f"rows_bd{bd}_{name}"] = rows
+    tables, index = [], np.full((19, 16), -1, np.int32)
+    seen = {}
+    for ts, (w, h) in enumerate(svtav1_hip.TX_SIZES_WH):
+        n = min(w, 32) * min(h, 32)
+        for tt in range(16):
+            scan = np.zeros(n, np.int16); iscan = np.zeros(n, np.int16)
+            got = me.ref_scan_order(ts, tt, C.c_void_p(scan.ctypes.data), C.c_void_p(iscan.ctypes.data))
+            if got == 0:
+                continue
+            assert got == n
+            key = scan.tobytes()
+            if key not in seen:
+                seen[key] = len(tables)
+                tables.append((scan, iscan))
+            index[ts, tt] = seen[key]
+    out["scan_index"] = index
+    out["scan_offsets"] = np.cumsum([0] + [len(t[0]) for t in tables]).astype(np.int32)
+    out["scan_pool"] = np.concatenate([t[0] for t in tables])
+    out["iscan_pool"] = np.concatenate([t[1] for t in tables])
+    np.savez_compressed(os.path.join(HERE, "quant_tables.npz"), **out)
+
+
 if __name__ == "__main__":
+    quant_tables_fixture()
     fullpel209_fixture()
     transform_fixture()
     fullpel_fixture()

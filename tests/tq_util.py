@@ -203,3 +203,67 @@ def oracle_encode_batch(oracle, b):
             out["dqcoeff"].ctypes.data + 4 * co, out["eob"].ctypes.data + 2 * i, out["energy"].ctypes.data + 8 * i,
             out["dist"].ctypes.data + 16 * i)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's REAL quantiser rows and scan orders (tests/golden/quant_tables.npz, generated by tests/golden/make_golden.py from
+# av1_build_quantizer / av1_scan_orders)
+# ---------------------------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quant_tables.npz")
+
+
+class RealTables:
+    def __init__(self):
+        z = np.load(_GOLDEN)
+        self.z = z
+        self.scan_index, self.scan_offsets = z["scan_index"], z["scan_offsets"]
+        self.scan_pool, self.iscan_pool = z["scan_pool"], z["iscan_pool"]
+
+    def rows(self, bit_depth=8, kind="inter"):
+        """[256][3][10] int16: zbin[2], round[2], quant[2], quant_shift[2], dequant[2] per (qindex, plane)."""
+        return self.z[f"rows_bd{bit_depth}_{kind}"]
+
+    def scan_offset(self, tx_size_index, tx_type):
+        """element offset of the (scan, iscan) pair of av1_scan_orders[tx_size][tx_type] in scan_pool / iscan_pool"""
+        k = int(self.scan_index[tx_size_index, tx_type])
+        assert k >= 0
+        return int(self.scan_offsets[k])
+
+
+def frame_encode_batch(rng, w, h, pic_w, pic_h, tables, qindices=(20, 120, 200), tx_types=None, residual="laplace", bit_depth=8,
+                       kind="inter"):
+    """One picture tiled completely by w x h TUs (1920x1080 -> 129 600 4x4 ... 510 64x64), prediction =
+    source + residual, real quantiser rows (luma plane of `qindices`) and the real scan order of every TU's transform type."""
+    ts = svtav1_hip.TX_SIZES_WH.index((w, h))
+    win, hin = min(w, 32), min(h, 32)
+    n = win * hin
+    cols, rows_ = pic_w // w, pic_h // h
+    n_tu = cols * rows_
+    sc = 1 << (bit_depth - 8)
+    dt = np.uint8 if bit_depth == 8 else np.uint16
+    yy, xx = np.mgrid[0:pic_h, 0:pic_w]
+    src = np.clip(sc * (128 + 70 * np.sin(xx / 9.0) * np.cos(yy / 7.0)), 0, 256 * sc - 1)
+    if residual == "laplace":
+        r = rng.laplace(0, 6 * sc, (pic_h, pic_w))
+    else:
+        r = rng.integers(-255 * sc, 255 * sc + 1, (pic_h, pic_w))
+    pred = np.clip(src - r, 0, 256 * sc - 1).astype(dt)
+    src = src.astype(dt)
+    if tx_types is None:
+        tx_types = [t for t in (0, 3, 9) if t in svtav1_hip.valid_tx_types(w, h)]  # DCT_DCT, ADST_ADST, IDTX
+    qrows = np.ascontiguousarray(tables.rows(bit_depth, kind)[list(qindices), 0, :])   # luma rows
+    idx = np.arange(n_tu)
+    off = (idx // cols) * h * pic_w + (idx % cols) * w
+    desc = np.zeros(n_tu, dtype=svtav1_hip.TU_DESC_DTYPE)
+    desc["src_offset"] = desc["pred_offset"] = desc["recon_offset"] = off
+    desc["coeff_offset"] = idx * n
+    tt = np.asarray(tx_types)[rng.integers(0, len(tx_types), n_tu)]
+    desc["tx_type"] = tt
+    desc["iscan_offset"] = np.asarray([tables.scan_offset(ts, int(t)) for t in tx_types])[np.searchsorted(np.asarray(tx_types), tt)] \
+        if sorted(tx_types) == list(tx_types) else [tables.scan_offset(ts, int(t)) for t in tt]
+    desc["src_stride"] = desc["pred_stride"] = desc["recon_stride"] = pic_w
+    desc["qparam_index"] = rng.integers(0, len(qindices), n_tu)
+    return {"src": src.reshape(-1), "pred": pred.reshape(-1), "desc": desc, "qparams": qrows, "scan": tables.scan_pool,
+            "iscan": tables.iscan_pool, "w": w, "h": h, "n": n, "bit_depth": bit_depth}
