@@ -37,8 +37,12 @@ extern "C" {
 typedef struct svthip_ctx svthip_ctx;
 
 /* One context per ME/EncDec thread context (MeContext_t / EncDecContext_t): owns a HIP stream and
- * device scratch; re-entrant across contexts (SURVEY 8b threading).  Created where the reference
- * builds MeContext_t (Codec/EbMotionEstimationContext.c:28-122). */
+ * device scratch; re-entrant across contexts (SURVEY 8b threading): any number of threads may call concurrently, each on
+ * its own context, with no lock on the hot path.  ONE context is used by one thread at a time.  Every entry makes the
+ * context's device current for the calling thread.  Entries that use context-owned scratch (the whole-picture ME, the
+ * 209-PU bi-prediction, the host-pointer forms) order themselves on the stream they are given: if a call passes a different
+ * stream than the previous scratch-using call of the same context, the new stream waits for the old one's work.
+ * Created where the reference builds MeContext_t (Codec/EbMotionEstimationContext.c:28-122). */
 int32_t svthip_create(int32_t device, svthip_ctx **out_ctx);
 void svthip_destroy(svthip_ctx *ctx);
 const char *svthip_last_error(void);
@@ -160,19 +164,6 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx *ctx, const uint8_t *d_
                                               uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
                                               const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
                                               int16_t *d_center, int16_t *d_hme_state, void *stream);
-
-/* Search centres AND the 85-PU full-pel search of the same superblocks in one fused launch: MotionEstimateLcu from the
- * centre check to the end of FullPelSearch_LCU (Source/Lib/Codec/EbMotionEstimation.c:6300-6760) for one reference list.
- * Arguments as svthip_me_hme_search_center_batch_dev, plus d_best_sad / d_best_mv [n_jobs * n_sb][85] (the outputs of
- * svthip_me_fullpel_search_dev run on the descriptors this call also writes to d_desc).  Bit-identical to the two
- * separate calls; the descriptor stays in LDS and the latency-bound centre chain of one workgroup overlaps the VALU-bound
- * full-pel search of its CU neighbours. */
-int32_t svthip_me_integer_search_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
-                                           const svthip_pa_picture *ref, uint32_t n_jobs, const svthip_me_params *params,
-                                           uint32_t list_index, const svthip_sb_origin *d_sb, uint32_t n_sb,
-                                           const uint32_t *d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc *d_desc,
-                                           int16_t *d_center, int16_t *d_hme_state, uint32_t *d_best_sad, uint32_t *d_best_mv,
-                                           void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sub-pel refinement (half-pel then quarter-pel) of the 85 square PUs of a batch of superblocks, one list.
@@ -436,6 +427,54 @@ int32_t svthip_pa_derive_planes_dev(svthip_ctx *ctx, uint8_t *d_pool, const svth
  * (pad_width, pad_height) is read, the border is written. */
 int32_t svthip_pad_plane_dev(svthip_ctx *ctx, void *d_plane, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_width,
                              uint32_t pad_height, uint32_t sample_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reference-layout results and host-pointer forms (what a C host that owns host memory binds).
+ *
+ * svthip_me_cu_result_ref has the memory layout of the reference's MeCuResults_t (Codec/EbMotionEstimationLcuResults.h:56-76) as
+ * GCC lays it out on x86-64: the four MV components, then three DistDir_t { unsigned distortion : 32; unsigned direction : 2; }
+ * (8 bytes each: the distortion word, then a word whose 2 low bits are the direction), then totalMeCandidateIndex -- 40 bytes.
+ * A host may hand its own MeCuResults_t arrays to the calls below; unused bits / padding bytes are written as 0. */
+typedef struct svthip_me_cu_result_ref {
+    int16_t xMvL0, yMvL0, xMvL1, yMvL1;
+    struct {
+        uint32_t distortion;
+        uint32_t direction; /* 0 = UNI_PRED_LIST_0, 1 = UNI_PRED_LIST_1, 2 = BI_PRED (only the 2 low bits are defined in the reference) */
+    } distortionDirection[3];
+    uint8_t totalMeCandidateIndex;
+    uint8_t pad_[7];
+} svthip_me_cu_result_ref;
+
+/* d_in [n] svthip_me_cu_result -> d_out [n] svthip_me_cu_result_ref */
+int32_t svthip_me_results_to_ref_layout_dev(svthip_ctx *ctx, const svthip_me_cu_result *d_in, uint32_t n, svthip_me_cu_result_ref *d_out,
+                                            void *stream);
+
+/* The fields of an EbPictureBufferDesc_t (Codec/EbPictureBufferDesc.h) the host-pointer ME entry reads: the padded luma plane of
+ * an EbPaReferenceObject_t::inputPaddedPicturePtr.  origin_x / origin_y must be 68 (Codec/EbEncHandle.c:1006-1009). */
+typedef struct svthip_host_picture {
+    const uint8_t *buffer_y;
+    uint32_t stride_y;
+    uint16_t origin_x, origin_y;
+    uint16_t width, height;
+} svthip_host_picture;
+
+/* MotionEstimationKernel's SB loop (Codec/EbMotionEstimationProcess.c:478-556) for one whole picture with HOST buffers: uploads the
+ * three luma planes (picture rows only), derives borders and the 1/4 and 1/16 planes on the device (svthip_pa_derive_planes_dev),
+ * runs svthip_motion_estimate[209]_batch_dev over every SB in raster order, and writes me_results[sb][pu] in the reference's own
+ * MeCuResults_t layout: me_results is the picture's `MeCuResults_t **me_results` (PictureParentControlSet_t), n_sb row pointers of
+ * n_pu (85 or 209) records each.  ref1 = NULL for P pictures.  Synchronous; the host buffers are authoritative on return. */
+int32_t svthip_motion_estimate_picture(svthip_ctx *ctx, const svthip_host_picture *cur, const svthip_host_picture *ref0,
+                                       const svthip_host_picture *ref1, const svthip_me_params *params, int32_t use_subpel_flag,
+                                       int32_t cu8x8_mode, uint32_t n_pu, void *const *me_results);
+
+/* svthip_encode_tu_batch_dev with HOST buffers: planes of `plane_samples` samples each (8-bit when planes_16bit == 0, else 16-bit),
+ * recon may alias pred (in-place reconstruction); qparams has n_qparam_rows rows of 10 int16; iscan n_iscan int16 entries;
+ * coefficient outputs hold coeff_samples int32 each (qcoeff required; coeff / dqcoeff / three_quad_energy / distortion may be NULL).
+ * Copies in, runs the fused chain, copies out and synchronises. */
+int32_t svthip_encode_tu_batch(svthip_ctx *ctx, const void *src, const void *pred, void *recon, size_t plane_samples, int32_t planes_16bit,
+                               const svthip_tu_desc *desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height, const int16_t *qparams,
+                               uint32_t n_qparam_rows, const int16_t *iscan, uint32_t n_iscan, size_t coeff_samples, int32_t *coeff,
+                               int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, uint64_t *three_quad_energy, uint64_t *distortion);
 
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */

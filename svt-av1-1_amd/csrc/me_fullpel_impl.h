@@ -1,6 +1,5 @@
 // svt-av1-1_amd/csrc/me_fullpel_impl.h -- 85-PU full-pel search of one superblock by one 256-thread workgroup (device code).
-// Included inside namespace svthip { namespace { ... } } by me_fullpel.hip (stand-alone kernel) and me_search.hip (fused with
-// the search-centre chain).  See me_fullpel.hip for the mapping and the reference citations.
+// Included inside namespace svthip { namespace { ... } } by me_fullpel.hip.  See me_fullpel.hip for the mapping and the reference citations.
 #pragma once
 
 

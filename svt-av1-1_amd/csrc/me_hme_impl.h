@@ -1,6 +1,6 @@
 // svt-av1-1_amd/csrc/me_hme_impl.h -- search-centre derivation of one superblock by one 256-thread workgroup (device code).
-// Included inside namespace svthip { namespace { ... } } by me_hme.hip (stand-alone kernel) and me_search.hip (fused with the
-// full-pel search).  See me_hme.hip for the mapping and the reference citations.
+// Included inside namespace svthip { namespace { ... } } by me_hme.hip.  (A kernel fusing this chain with the full-pel
+// search of the same superblock was bit-identical but slower -- both halves are VALU-bound -- and was removed.)  See me_hme.hip for the mapping and the reference citations.
 #pragma once
 
 

@@ -37,6 +37,7 @@ struct PaJobTable {
     svthip_pa_picture pic[SVTHIP_HME_MAX_JOBS];
 };
 __global__ void pa_derive_planes_kernel(uint8_t* __restrict__ pool, PaJobTable jobs, int do_quarter, int do_sixteenth);
+__global__ void me_results_ref_layout_kernel(const svthip_me_cu_result* __restrict__ in, uint32_t n, svthip_me_cu_result_ref* __restrict__ out);
 hipError_t launch_pad_plane(void* plane, uint32_t stride, int width, int height, int pad_w, int pad_h, int sample_bytes, hipStream_t s);
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
@@ -90,12 +91,6 @@ __global__ void fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_
                                   uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
                                   uint32_t* __restrict__ out_mv);
 size_t fullpel209_lds_bytes(uint32_t max_sh);
-
-__global__ void me_search_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P, uint32_t list_index,
-                                 const svthip_sb_origin* __restrict__ sbs, const uint32_t* __restrict__ l0_best_mv64,
-                                 uint32_t l0_mv_stride, svthip_fullpel_desc* __restrict__ out_desc, int16_t* __restrict__ out_center,
-                                 int16_t* __restrict__ hme_state, uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv);
-size_t me_search_lds_bytes(uint32_t max_sh);
 
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 

@@ -118,4 +118,24 @@ hipError_t launch_pad_plane(void* plane, uint32_t stride, int width, int height,
     return hipGetLastError();
 }
 
+// svthip_me_cu_result (24 B) -> the reference's MeCuResults_t layout (40 B, Codec/EbMotionEstimationLcuResults.h:56-76)
+__global__ void __launch_bounds__(256) me_results_ref_layout_kernel(const svthip_me_cu_result* __restrict__ in, uint32_t n,
+                                                                     svthip_me_cu_result_ref* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const svthip_me_cu_result r = in[i];
+    svthip_me_cu_result_ref o;
+    o.xMvL0 = r.xMvL0; o.yMvL0 = r.yMvL0; o.xMvL1 = r.xMvL1; o.yMvL1 = r.yMvL1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.distortionDirection[k].distortion = r.distortion[k];
+        o.distortionDirection[k].direction = r.direction[k];
+    }
+    o.totalMeCandidateIndex = r.totalMeCandidateIndex;
+#pragma unroll
+    for (int k = 0; k < 7; k++) o.pad_[k] = 0;
+    out[i] = o;
+}
+
 }  // namespace svthip

@@ -34,16 +34,65 @@ int32_t fail(int32_t code, const char* fmt, const char* a = "", int b = 0)
 struct svthip_ctx {
     int device;
     hipStream_t stream;
-    // grow-only device scratch for the host-pointer entry points
-    void* scratch[8];
-    size_t scratch_bytes[8];
-    int max_dyn_lds_set;
-    int max_dyn_lds_search;
-    int max_dyn_lds_209;
+    // grow-only device scratch: slots 0-4 host-pointer full-pel form, 5 per-list ME arrays, 6 bi-pred SADs, 7 stored predictions,
+    // 8-15 host-pointer picture / TU forms
+    void* scratch[16];
+    size_t scratch_bytes[16];
+    // the stream the context-owned scratch was last used on, and an event to order a different stream behind it
+    hipStream_t scratch_stream;
+    hipEvent_t scratch_event;
 };
 
 namespace {
 
+// One-time, process-wide, per device: every kernel that takes dynamic LDS gets its limit raised to what the largest legal launch needs
+// (160 KB minus the kernel's static LDS).  hipFuncSetAttribute is per-FUNCTION state, so it must not be cached per context: a second
+// context with a smaller search area would lower the limit under a first one's launches (round-1 defect).
+std::once_flag g_attr_once[16];
+hipError_t g_attr_status[16];
+
+void set_kernel_attrs(int device)
+{
+    const void* kernels[] = {reinterpret_cast<const void*>(svthip::fullpel85_kernel),  reinterpret_cast<const void*>(svthip::fullpel209_kernel),
+                             reinterpret_cast<const void*>(svthip::subpel85_kernel),   reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
+                             reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel)};
+    hipError_t st = hipSuccess;
+    for (const void* k : kernels) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, k);
+        if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+        if (e != hipSuccess) st = e;
+    }
+    g_attr_status[device] = st;
+}
+
+// entry prologue of every call: the context's device becomes current for the calling thread
+int32_t enter(svthip_ctx* c)
+{
+    if (!c) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    HIP_TRY(hipSetDevice(c->device));
+    return SVTHIP_OK;
+}
+#define ENTER(ctx)                         \
+    do {                                   \
+        int32_t rc_ = enter(ctx);          \
+        if (rc_) return rc_;               \
+    } while (0)
+
+// Context-owned scratch is about to be used by work enqueued on `s`: if the previous user was a different stream, order `s` behind it
+// (a caller may hand any stream to a `_dev` entry; two in-flight calls of one context on two streams then serialise instead of racing).
+int32_t scratch_on_stream(svthip_ctx* c, hipStream_t s)
+{
+    if (c->scratch_stream && c->scratch_stream != s) {
+        HIP_TRY(hipEventRecord(c->scratch_event, c->scratch_stream));
+        HIP_TRY(hipStreamWaitEvent(s, c->scratch_event, 0));
+    }
+    c->scratch_stream = s;
+    return SVTHIP_OK;
+}
+
+// Growing a slot frees the old buffer; hipFree synchronises the device first, so work still reading it has finished (growth is rare:
+// the slots only ever grow).
 int32_t ensure_scratch(svthip_ctx* c, int slot, size_t bytes)
 {
     if (c->scratch_bytes[slot] >= bytes) return SVTHIP_OK;
@@ -61,7 +110,7 @@ int32_t launch_fullpel(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_strid
                        const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_sw, uint32_t max_sh,
                        uint32_t* d_sad, uint32_t* d_mv, hipStream_t s)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0) return SVTHIP_OK;
     if (!d_src || !d_ref || !d_desc || !d_sad || !d_mv) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (max_sw < 1 || max_sw > 127 || max_sh < 1 || max_sh > 127)
@@ -69,11 +118,6 @@ int32_t launch_fullpel(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_strid
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     const size_t lds = svthip::fullpel_lds_bytes(max_sh);
-    if ((int)lds > ctx->max_dyn_lds_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::fullpel85_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->max_dyn_lds_set = (int)lds;
-    }
     hipLaunchKernelGGL(svthip::fullpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src, src_stride, d_ref, ref_stride,
                        reinterpret_cast<const int32_t*>(d_desc), d_sad, d_mv);
     HIP_TRY(hipGetLastError());
@@ -94,7 +138,11 @@ int32_t svthip_create(int32_t device, svthip_ctx** out_ctx)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(SVTHIP_ERR_DEVICE, "no HIP device available%s (this library has no CPU fallback)", "");
     if (device < 0 || device >= n) return fail(SVTHIP_ERR_BAD_PARAMETER, "device index out of range%s (%d)", "", device);
+    if (device >= 16) return fail(SVTHIP_ERR_BAD_PARAMETER, "device index above 15 is not supported%s (%d)", "", device);
     HIP_TRY(hipSetDevice(device));
+    std::call_once(g_attr_once[device], set_kernel_attrs, device);
+    if (g_attr_status[device] != hipSuccess)
+        return fail(SVTHIP_ERR_DEVICE, "raising the kernels' dynamic LDS limit failed: %s", hipGetErrorString(g_attr_status[device]));
     svthip_ctx* c = new (std::nothrow) svthip_ctx();
     if (!c) return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
     memset(c, 0, sizeof(*c));
@@ -102,6 +150,11 @@ int32_t svthip_create(int32_t device, svthip_ctx** out_ctx)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(SVTHIP_ERR_DEVICE, "hipStreamCreate failed%s", "");
+    }
+    if (hipEventCreateWithFlags(&c->scratch_event, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(SVTHIP_ERR_DEVICE, "hipEventCreate failed%s", "");
     }
     *out_ctx = c;
     return SVTHIP_OK;
@@ -112,8 +165,9 @@ void svthip_destroy(svthip_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 16; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    (void)hipEventDestroy(ctx->scratch_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -122,7 +176,7 @@ void* svthip_stream(svthip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr
 
 int32_t svthip_synchronize(svthip_ctx* ctx)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return SVTHIP_OK;
 }
@@ -132,7 +186,7 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
                                      uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
                                      uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     return launch_fullpel(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
                           max_search_area_height, d_best_sad, d_best_mv, s);
@@ -143,7 +197,7 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
                                      uint32_t max_search_area_height, int32_t disable_8x8_refinement, int n_pu, uint32_t* d_best_sad,
                                      uint32_t* d_best_mv, void* stream, uint32_t* d_pred = nullptr)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0) return SVTHIP_OK;
     if (!d_src_plane || !d_ref_plane || !d_desc || !d_best_sad || !d_best_mv)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
@@ -155,15 +209,11 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
     const size_t lds_nsq = svthip::subpel_nsq_lds_bytes(max_search_area_width, max_search_area_height);
     if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel85_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
                        reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv, d_pred, n_pu == 209 ? 14 : 4);
     HIP_TRY(hipGetLastError());
     if (n_pu == 209) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nsq));
         hipLaunchKernelGGL(svthip::subpel_nsq_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
                            reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv, d_pred);
         HIP_TRY(hipGetLastError());
@@ -196,7 +246,7 @@ static int32_t bipred_pack_common(svthip_ctx* ctx, const uint8_t* d_src_plane, u
                                   const uint32_t* d_mv0, const uint32_t* d_sad1, const uint32_t* d_mv1, uint32_t n_lists,
                                   int32_t bipred_8x8, int n_pu, svthip_me_cu_result* d_out, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0) return SVTHIP_OK;
     if (n_lists < 1 || n_lists > 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_lists must be 1 or 2%s", "");
     if (!d_sad0 || !d_mv0 || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
@@ -214,8 +264,6 @@ static int32_t bipred_pack_common(svthip_ctx* ctx, const uint8_t* d_src_plane, u
         win_bytes = (int)svthip::subpel_window_bytes(max_search_area_width, max_search_area_height);
         if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
             return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS windows%s", "");
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_pack_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (n_pu == 85) {
@@ -230,13 +278,12 @@ static int32_t bipred_pack_common(svthip_ctx* ctx, const uint8_t* d_src_plane, u
     if (n_lists == 2) {
         int32_t rc;
         if ((rc = ensure_scratch(ctx, 6, sizeof(uint32_t) * 85 * (size_t)n_sb))) return rc;
+        if ((rc = scratch_on_stream(ctx, s))) return rc;
         bisad_sq = static_cast<uint32_t*>(ctx->scratch[6]);
         hipLaunchKernelGGL(svthip::bipred_pack_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
                            reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
                            d_sad0, d_mv0, d_sad1, d_mv1, 2, 1, win_bytes, 209, bisad_sq, (svthip_me_cu_result*)nullptr);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nsq));
     }
     hipLaunchKernelGGL(svthip::bipred_nsq_pack_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref0_plane, ref0_stride,
                        reinterpret_cast<const int32_t*>(d_desc0), d_ref1_plane, ref1_stride, reinterpret_cast<const int32_t*>(d_desc1),
@@ -272,7 +319,7 @@ int32_t svthip_quantize_b_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff, con
                                     const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_qcoeff, int32_t* d_dqcoeff,
                                     uint16_t* d_eob, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_tu == 0) return SVTHIP_OK;
     if (!d_coeff || !d_desc || !d_qparams || !d_iscan || !d_qcoeff || !d_dqcoeff || !d_eob)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
@@ -292,7 +339,7 @@ int32_t svthip_me_fullpel_search209_dev(svthip_ctx* ctx, const uint8_t* d_src_pl
                                         uint32_t max_search_area_width, uint32_t max_search_area_height, uint32_t* d_best_sad,
                                         uint32_t* d_best_mv, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0) return SVTHIP_OK;
     if (!d_src_plane || !d_ref_plane || !d_desc || !d_best_sad || !d_best_mv) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (max_search_area_width < 1 || max_search_area_width > 127 || max_search_area_height < 1 || max_search_area_height > 127)
@@ -301,11 +348,6 @@ int32_t svthip_me_fullpel_search209_dev(svthip_ctx* ctx, const uint8_t* d_src_pl
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     const size_t lds = svthip::fullpel209_lds_bytes(max_search_area_height);
-    if ((int)lds > ctx->max_dyn_lds_209) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::fullpel209_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
-        ctx->max_dyn_lds_209 = (int)lds;
-    }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::fullpel209_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
                        reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv);
@@ -316,7 +358,7 @@ int32_t svthip_me_fullpel_search209_dev(svthip_ctx* ctx, const uint8_t* d_src_pl
 int32_t svthip_fwd_txfm2d_batch_dev(svthip_ctx* ctx, const int16_t* d_residual, const svthip_txfm_desc* d_desc, uint32_t n_tu,
                                     uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, int32_t* d_coeff, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
     if (bit_depth != 8 && bit_depth != 10) return fail(SVTHIP_ERR_BAD_PARAMETER, "bit_depth must be 8 or 10%s (got %d)", "", (int)bit_depth);
@@ -332,7 +374,7 @@ int32_t svthip_inv_txfm2d_add_batch_dev(svthip_ctx* ctx, const int32_t* d_coeff,
                                         uint32_t tx_width, uint32_t tx_height, uint32_t bit_depth, uint32_t recon_16bit,
                                         void* d_recon, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
     if (bit_depth != 8 && bit_depth != 10) return fail(SVTHIP_ERR_BAD_PARAMETER, "bit_depth must be 8 or 10%s (got %d)", "", (int)bit_depth);
@@ -352,7 +394,7 @@ static int32_t encode_tu_common(svthip_ctx* ctx, const void* d_src, const void* 
                                 const int16_t* d_qparams, const int16_t* d_iscan, int32_t* d_coeff, int32_t* d_qcoeff,
                                 int32_t* d_dqcoeff, uint16_t* d_eob, uint64_t* d_three_quad_energy, uint64_t* d_distortion, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
     if (n_tu == 0) return SVTHIP_OK;
@@ -391,16 +433,15 @@ int32_t svthip_encode_tu16_batch_dev(svthip_ctx* ctx, const uint16_t* d_src, con
                             d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, stream);
 }
 
-static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur, const svthip_pa_picture* ref,
-                                uint32_t n_jobs, const svthip_me_params* params, uint32_t list_index, const svthip_sb_origin* d_sb,
-                                uint32_t n_sb, const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
-                                int16_t* d_center, int16_t* d_hme_state, uint32_t* d_best_sad, uint32_t* d_best_mv, bool fused,
-                                void* stream)
+int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
+                                              const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
+                                              uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
+                                              const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
+                                              int16_t* d_center, int16_t* d_hme_state, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
     if (!d_pool || !cur || !ref || !params || !d_sb || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
-    if (fused && (!d_best_sad || !d_best_mv)) return fail(SVTHIP_ERR_BAD_PARAMETER, "null result pointer%s", "");
     if (list_index > 1) return fail(SVTHIP_ERR_BAD_PARAMETER, "list_index must be 0 or 1%s", "");
     if (list_index == 1 && !d_l0_best_mv64 && params->temporal_layer_index > 0)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "list 1 needs the list-0 64x64 MVs (hme_mv_center_check direct candidate)%s", "");
@@ -408,8 +449,6 @@ static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const sv
     if (P.number_hme_search_region_in_width < 1 || P.number_hme_search_region_in_width > 2 ||
         P.number_hme_search_region_in_height < 1 || P.number_hme_search_region_in_height > 2)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "HME search regions must be 1..2 per axis%s", "");
-    if (fused && (P.search_area_width < 1 || P.search_area_height < 1))
-        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be at least 1x1%s", "");
     for (uint32_t j = 0; j < n_jobs; j++) {
         const svthip_pa_picture *c = cur + j, *r = ref + j;
         if ((c->width & 7) || (c->height & 7) || c->width != r->width || c->height != r->height || c->width != cur->width ||
@@ -424,16 +463,6 @@ static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const sv
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const uint32_t mvs = l0_mv_stride ? l0_mv_stride : 1u;
-    size_t lds = 0;
-    if (fused) {
-        const uint32_t shh = P.search_area_height > 127 ? 127u : P.search_area_height;  // the kernel clamps the area to 127 (:6667)
-        lds = svthip::me_search_lds_bytes(shh);
-        if ((int)lds > ctx->max_dyn_lds_search) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(svthip::me_search_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ctx->max_dyn_lds_search = (int)lds;
-        }
-    }
     for (uint32_t j0 = 0; j0 < n_jobs; j0 += SVTHIP_HME_MAX_JOBS) {
         const uint32_t nj = (n_jobs - j0 < SVTHIP_HME_MAX_JOBS) ? n_jobs - j0 : SVTHIP_HME_MAX_JOBS;
         svthip::HmeJobTable jt;
@@ -446,36 +475,11 @@ static int32_t hme_batch_launch(svthip_ctx* ctx, const uint8_t* d_pool, const sv
         const uint32_t* mv64 = d_l0_best_mv64 ? d_l0_best_mv64 + base * mvs : nullptr;
         int16_t* cen = d_center ? d_center + 2 * base : nullptr;
         int16_t* st = d_hme_state ? d_hme_state + SVTHIP_HME_STATE_INT16 * base : nullptr;
-        if (fused)
-            hipLaunchKernelGGL(svthip::me_search_kernel, dim3(n_sb, nj), dim3(256), lds, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
-                               d_desc + base, cen, st, d_best_sad + 85 * base, d_best_mv + 85 * base);
-        else
-            hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
-                               d_desc + base, cen, st);
+        hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
+                           d_desc + base, cen, st);
         HIP_TRY(hipGetLastError());
     }
     return SVTHIP_OK;
-}
-
-int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                              const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
-                                              uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
-                                              const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
-                                              int16_t* d_center, int16_t* d_hme_state, void* stream)
-{
-    return hme_batch_launch(ctx, d_pool, cur, ref, n_jobs, params, list_index, d_sb, n_sb, d_l0_best_mv64, l0_mv_stride, d_desc, d_center,
-                            d_hme_state, nullptr, nullptr, false, stream);
-}
-
-int32_t svthip_me_integer_search_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
-                                           const svthip_pa_picture* ref, uint32_t n_jobs, const svthip_me_params* params,
-                                           uint32_t list_index, const svthip_sb_origin* d_sb, uint32_t n_sb,
-                                           const uint32_t* d_l0_best_mv64, uint32_t l0_mv_stride, svthip_fullpel_desc* d_desc,
-                                           int16_t* d_center, int16_t* d_hme_state, uint32_t* d_best_sad, uint32_t* d_best_mv,
-                                           void* stream)
-{
-    return hme_batch_launch(ctx, d_pool, cur, ref, n_jobs, params, list_index, d_sb, n_sb, d_l0_best_mv64, l0_mv_stride, d_desc, d_center,
-                            d_hme_state, d_best_sad, d_best_mv, true, stream);
 }
 
 int32_t svthip_me_hme_search_center_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur,
@@ -494,14 +498,13 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
                                             const svthip_sb_origin* d_sb, uint32_t n_sb, uint32_t n_pu, svthip_me_cu_result* d_out,
                                             uint32_t* d_list_sad, uint32_t* d_list_mv, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0 || n_jobs == 0) return SVTHIP_OK;
     if (!d_pool || !cur || !ref0 || !params || !d_sb || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     for (uint32_t j = 0; j < n_jobs; j++)  // the per-SB kernels take one stride per plane role
         if (cur[j].full_stride != cur[0].full_stride || ref0[j].full_stride != ref0[0].full_stride ||
             (ref1 && ref1[j].full_stride != ref1[0].full_stride))
             return fail(SVTHIP_ERR_BAD_PARAMETER, "all pictures of a batch must share their full-resolution strides%s (job %d)", "", (int)j);
-    HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n_lists = ref1 ? 2u : 1u;
     const size_t n = (size_t)n_jobs * n_sb;
     // scratch: slot 5 holds  desc[2][n] | sad[2][n][n_pu] | mv[2][n][n_pu] | hme_state[n][25]
@@ -519,6 +522,7 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
         mv[0] = d_list_mv; mv[1] = d_list_mv + n_pu * n;
     }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if ((rc = scratch_on_stream(ctx, s))) return rc;  // slots 5 / 7 are about to be used by work on `s`
     const uint32_t sw = params->search_area_width < 127 ? params->search_area_width : 127;
     const uint32_t sh = params->search_area_height < 127 ? params->search_area_height : 127;
     const svthip_pa_picture* refs[2] = {ref0, ref1};
@@ -593,11 +597,10 @@ int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size
                                  const uint8_t* ref_plane, size_t ref_plane_bytes, uint32_t ref_stride,
                                  const svthip_fullpel_desc* desc, uint32_t n_sb, uint32_t* best_sad, uint32_t* best_mv)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_sb == 0) return SVTHIP_OK;
     if (!src_plane || !ref_plane || !desc || !best_sad || !best_mv)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
-    HIP_TRY(hipSetDevice(ctx->device));
     uint32_t max_sw = 1, max_sh = 1;
     for (uint32_t i = 0; i < n_sb; i++) {
         const svthip_fullpel_desc& d = desc[i];
@@ -634,10 +637,9 @@ int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size
 int32_t svthip_pa_derive_planes_dev(svthip_ctx* ctx, uint8_t* d_pool, const svthip_pa_picture* pics, uint32_t n_pics, int32_t want_quarter,
                                     int32_t want_sixteenth, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (n_pics == 0) return SVTHIP_OK;
     if (!d_pool || !pics) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
-    HIP_TRY(hipSetDevice(ctx->device));
     uint32_t max_dw = 0;
     for (uint32_t j = 0; j < n_pics; j++) {
         const svthip_pa_picture& p = pics[j];
@@ -669,15 +671,163 @@ int32_t svthip_pa_derive_planes_dev(svthip_ctx* ctx, uint8_t* d_pool, const svth
 int32_t svthip_pad_plane_dev(svthip_ctx* ctx, void* d_plane, uint32_t stride, uint32_t width, uint32_t height, uint32_t pad_width,
                              uint32_t pad_height, uint32_t sample_bytes, void* stream)
 {
-    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    ENTER(ctx);
     if (!d_plane) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (sample_bytes != 1 && sample_bytes != 2) return fail(SVTHIP_ERR_BAD_PARAMETER, "sample_bytes must be 1 or 2%s (got %d)", "", (int)sample_bytes);
     if (width == 0 || height == 0 || stride < width + 2 * pad_width || width > 16384 || height > 16384 || pad_width > 1024 || pad_height > 1024)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "bad plane geometry%s (stride %d)", "", (int)stride);
     if (sample_bytes == 2 && (reinterpret_cast<uintptr_t>(d_plane) & 1u)) return fail(SVTHIP_ERR_BAD_PARAMETER, "16-bit plane must be 2-byte aligned%s", "");
-    HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(svthip::launch_pad_plane(d_plane, stride, (int)width, (int)height, (int)pad_width, (int)pad_height, (int)sample_bytes, s));
+    return SVTHIP_OK;
+}
+
+int32_t svthip_me_results_to_ref_layout_dev(svthip_ctx* ctx, const svthip_me_cu_result* d_in, uint32_t n, svthip_me_cu_result_ref* d_out,
+                                            void* stream)
+{
+    ENTER(ctx);
+    if (n == 0) return SVTHIP_OK;
+    if (!d_in || !d_out) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::me_results_ref_layout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_in, n, d_out);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
+int32_t svthip_motion_estimate_picture(svthip_ctx* ctx, const svthip_host_picture* cur, const svthip_host_picture* ref0,
+                                       const svthip_host_picture* ref1, const svthip_me_params* params, int32_t use_subpel_flag,
+                                       int32_t cu8x8_mode, uint32_t n_pu, void* const* me_results)
+{
+    ENTER(ctx);
+    if (!cur || !ref0 || !params || !me_results) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (n_pu != 85 && n_pu != 209) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_pu must be 85 or 209%s (got %d)", "", (int)n_pu);
+    const svthip_host_picture* hp[3] = {cur, ref0, ref1};
+    const int n_pic = ref1 ? 3 : 2;
+    const uint32_t w = cur->width, h = cur->height;
+    if ((w & 7) || (h & 7) || !w || !h) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be non-zero multiples of 8%s", "");
+    for (int i = 0; i < n_pic; i++) {
+        if (!hp[i]->buffer_y || hp[i]->width != w || hp[i]->height != h || hp[i]->origin_x != 68 || hp[i]->origin_y != 68 ||
+            hp[i]->stride_y < w + 136u)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "picture %s%d: needs a luma plane of the same size with origin (68,68) and stride >= width + 136", "", i);
+    }
+    // device pool: per picture the padded full plane (stride = width + 136), the 1/4 and the 1/16 plane
+    const uint32_t fs = w + 136, qs = (w >> 1) + 64, ss = (w >> 2) + 32;
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t fb = al((size_t)fs * (h + 136)), qb = al((size_t)qs * ((h >> 1) + 64)), sb_ = al((size_t)ss * ((h >> 2) + 32));
+    const size_t per = fb + qb + sb_;
+    const uint32_t nx = (w + 63) / 64, ny = (h + 63) / 64, n_sb = nx * ny;
+    int32_t rc;
+    if ((rc = ensure_scratch(ctx, 8, per * n_pic + 256))) return rc;
+    if ((rc = ensure_scratch(ctx, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
+    if ((rc = ensure_scratch(ctx, 10, sizeof(svthip_me_cu_result) * (size_t)n_sb * n_pu))) return rc;
+    if ((rc = ensure_scratch(ctx, 11, sizeof(svthip_me_cu_result_ref) * (size_t)n_sb * n_pu))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = scratch_on_stream(ctx, s))) return rc;
+    uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
+    svthip_pa_picture pd[3];
+    for (int i = 0; i < n_pic; i++) {
+        pd[i].full_offset = (int64_t)(per * i);
+        pd[i].quarter_offset = (int64_t)(per * i + fb);
+        pd[i].sixteenth_offset = (int64_t)(per * i + fb + qb);
+        pd[i].full_stride = fs; pd[i].quarter_stride = qs; pd[i].sixteenth_stride = ss;
+        pd[i].width = (uint16_t)w; pd[i].height = (uint16_t)h;
+        // the picture rows only (borders and decimated planes are derived on the device, bit-identically to Picture Analysis)
+        HIP_TRY(hipMemcpy2DAsync(pool + per * i + (size_t)68 * fs + 68, fs, hp[i]->buffer_y + (size_t)68 * hp[i]->stride_y + 68, hp[i]->stride_y,
+                                 w, h, hipMemcpyHostToDevice, s));
+    }
+    svthip_sb_origin* sbs = new (std::nothrow) svthip_sb_origin[n_sb];
+    if (!sbs) return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
+    for (uint32_t y = 0; y < ny; y++)
+        for (uint32_t x = 0; x < nx; x++) sbs[y * nx + x] = svthip_sb_origin{(uint16_t)(x * 64), (uint16_t)(y * 64)};
+    hipError_t e = hipMemcpyAsync(ctx->scratch[9], sbs, sizeof(svthip_sb_origin) * n_sb, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // sbs is pageable: the copy has left it before it is freed
+    delete[] sbs;
+    HIP_TRY(e);
+    if ((rc = svthip_pa_derive_planes_dev(ctx, pool, pd, (uint32_t)n_pic, params->enable_hme_level1_flag, params->enable_hme_level0_flag, s))) return rc;
+    svthip_me_cu_result* d_res = static_cast<svthip_me_cu_result*>(ctx->scratch[10]);
+    rc = n_pu == 209 ? svthip_motion_estimate209_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode,
+                                                           static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb, d_res, nullptr, nullptr, s)
+                     : svthip_motion_estimate_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode,
+                                                        static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb, d_res, nullptr, nullptr, s);
+    if (rc) return rc;
+    svthip_me_cu_result_ref* d_ref = static_cast<svthip_me_cu_result_ref*>(ctx->scratch[11]);
+    if ((rc = svthip_me_results_to_ref_layout_dev(ctx, d_res, n_sb * n_pu, d_ref, s))) return rc;
+    for (uint32_t i = 0; i < n_sb; i++) {
+        if (!me_results[i]) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results[%s%d] is null", "", (int)i);
+        HIP_TRY(hipMemcpyAsync(me_results[i], d_ref + (size_t)i * n_pu, sizeof(svthip_me_cu_result_ref) * n_pu, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    return SVTHIP_OK;
+}
+
+int32_t svthip_encode_tu_batch(svthip_ctx* ctx, const void* src, const void* pred, void* recon, size_t plane_samples, int32_t planes_16bit,
+                               const svthip_tu_desc* desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height, const int16_t* qparams,
+                               uint32_t n_qparam_rows, const int16_t* iscan, uint32_t n_iscan, size_t coeff_samples, int32_t* coeff,
+                               int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob, uint64_t* three_quad_energy, uint64_t* distortion)
+{
+    ENTER(ctx);
+    if (n_tu == 0) return SVTHIP_OK;
+    if (!src || !pred || !recon || !desc || !qparams || !iscan || !qcoeff || !eob || !plane_samples || !coeff_samples || !n_qparam_rows || !n_iscan)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer / empty buffer argument%s", "");
+    if (!svthip::fwd_txfm2d_size_valid((int)tx_width, (int)tx_height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "unsupported transform size%s (width %d)", "", (int)tx_width);
+    const size_t es = planes_16bit ? 2 : 1, pb = plane_samples * es;
+    const uint32_t win = tx_width > 32 ? 32 : tx_width, hin = tx_height > 32 ? 32 : tx_height;
+    for (uint32_t i = 0; i < n_tu; i++) {  // the kernel trusts its descriptors: check them against the buffers the caller declared
+        const svthip_tu_desc& d = desc[i];
+        const size_t last = (size_t)(tx_height - 1);
+        if ((size_t)d.src_offset + last * d.src_stride + tx_width > plane_samples || (size_t)d.pred_offset + last * d.pred_stride + tx_width > plane_samples ||
+            (size_t)d.recon_offset + last * d.recon_stride + tx_width > plane_samples)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "desc[%s%d]: block outside the planes", "", (int)i);
+        if ((d.coeff_offset & 3u) || (size_t)d.coeff_offset + (size_t)win * hin > coeff_samples)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "desc[%s%d]: coefficient block outside the pools or not 4-aligned", "", (int)i);
+        if ((d.iscan_offset & 3u) || (size_t)d.iscan_offset + (size_t)win * hin > n_iscan || d.qparam_index >= n_qparam_rows)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "desc[%s%d]: scan table / quantiser row out of range", "", (int)i);
+    }
+    const bool in_place = recon == pred;
+    const size_t cb = coeff_samples * sizeof(int32_t);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // slot 12: src | pred | recon planes; 13: desc | qparams | iscan; 14: coeff | qcoeff | dqcoeff; 15: eob | energy | dist
+    int32_t rc;
+    if ((rc = ensure_scratch(ctx, 12, al(pb) * 3))) return rc;
+    if ((rc = ensure_scratch(ctx, 13, al(sizeof(svthip_tu_desc) * n_tu) + al(20 * (size_t)n_qparam_rows) + al(2 * (size_t)n_iscan)))) return rc;
+    if ((rc = ensure_scratch(ctx, 14, al(cb) * 3))) return rc;
+    if ((rc = ensure_scratch(ctx, 15, al(2 * (size_t)n_tu) + al(8 * (size_t)n_tu) + al(16 * (size_t)n_tu)))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = scratch_on_stream(ctx, s))) return rc;
+    uint8_t* p12 = static_cast<uint8_t*>(ctx->scratch[12]);
+    uint8_t *d_src = p12, *d_pred = p12 + al(pb), *d_recon = in_place ? d_pred : p12 + 2 * al(pb);
+    uint8_t* p13 = static_cast<uint8_t*>(ctx->scratch[13]);
+    svthip_tu_desc* d_desc = reinterpret_cast<svthip_tu_desc*>(p13);
+    int16_t* d_qp = reinterpret_cast<int16_t*>(p13 + al(sizeof(svthip_tu_desc) * n_tu));
+    int16_t* d_iscan = reinterpret_cast<int16_t*>(p13 + al(sizeof(svthip_tu_desc) * n_tu) + al(20 * (size_t)n_qparam_rows));
+    uint8_t* p14 = static_cast<uint8_t*>(ctx->scratch[14]);
+    int32_t *d_coeff = coeff ? reinterpret_cast<int32_t*>(p14) : nullptr, *d_q = reinterpret_cast<int32_t*>(p14 + al(cb)),
+            *d_dq = dqcoeff ? reinterpret_cast<int32_t*>(p14 + 2 * al(cb)) : nullptr;
+    uint8_t* p15 = static_cast<uint8_t*>(ctx->scratch[15]);
+    uint16_t* d_eob = reinterpret_cast<uint16_t*>(p15);
+    uint64_t* d_en = three_quad_energy ? reinterpret_cast<uint64_t*>(p15 + al(2 * (size_t)n_tu)) : nullptr;
+    uint64_t* d_dist = distortion ? reinterpret_cast<uint64_t*>(p15 + al(2 * (size_t)n_tu) + al(8 * (size_t)n_tu)) : nullptr;
+    HIP_TRY(hipMemcpyAsync(d_src, src, pb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_pred, pred, pb, hipMemcpyHostToDevice, s));
+    if (!in_place) HIP_TRY(hipMemcpyAsync(d_recon, recon, pb, hipMemcpyHostToDevice, s));  // samples outside the TUs keep the caller's values
+    HIP_TRY(hipMemcpyAsync(d_desc, desc, sizeof(svthip_tu_desc) * n_tu, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_qp, qparams, 20 * (size_t)n_qparam_rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_iscan, iscan, 2 * (size_t)n_iscan, hipMemcpyHostToDevice, s));
+    // pool words no TU covers come back as the caller left them
+    if (coeff) HIP_TRY(hipMemcpyAsync(d_coeff, coeff, cb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_q, qcoeff, cb, hipMemcpyHostToDevice, s));
+    if (dqcoeff) HIP_TRY(hipMemcpyAsync(d_dq, dqcoeff, cb, hipMemcpyHostToDevice, s));
+    HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit ? 1 : 0, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qp, d_iscan, d_coeff,
+                                     d_q, d_dq, d_eob, d_en, d_dist, s));
+    HIP_TRY(hipMemcpyAsync(recon, d_recon, pb, hipMemcpyDeviceToHost, s));
+    if (coeff) HIP_TRY(hipMemcpyAsync(coeff, d_coeff, cb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(qcoeff, d_q, cb, hipMemcpyDeviceToHost, s));
+    if (dqcoeff) HIP_TRY(hipMemcpyAsync(dqcoeff, d_dq, cb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(eob, d_eob, 2 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+    if (three_quad_energy) HIP_TRY(hipMemcpyAsync(three_quad_energy, d_en, 8 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+    if (distortion) HIP_TRY(hipMemcpyAsync(distortion, d_dist, 16 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SVTHIP_OK;
 }
 
@@ -688,7 +838,6 @@ int32_t svthip_me_fullpel_search_time_dev(svthip_ctx* ctx, const uint8_t* d_src_
                                           uint32_t iters, float* avg_ms)
 {
     if (!ctx || !avg_ms || iters == 0) return fail(SVTHIP_ERR_BAD_PARAMETER, "bad timing arguments%s", "");
-    HIP_TRY(hipSetDevice(ctx->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));

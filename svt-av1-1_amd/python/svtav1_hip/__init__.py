@@ -71,10 +71,6 @@ def lib() -> C.CDLL:
     L.svthip_me_hme_search_center_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
                                                         C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                                         C.c_void_p, C.c_void_p, C.c_void_p]
-    L.svthip_me_integer_search_batch_dev.restype = C.c_int32
-    L.svthip_me_integer_search_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p,
-                                                     C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
-                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.svthip_motion_estimate_picture_dev.restype = C.c_int32
     L.svthip_motion_estimate_picture_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -204,16 +200,6 @@ def _hme_search_center_batch_dev(self, d_pool, curs, refs, params, list_index, d
                                                        l0_mv_stride, d_desc, d_center, d_state, stream))
 
 
-def _integer_search_batch_dev(self, d_pool, curs, refs, params, list_index, d_sb, n_sb, d_l0_mv64, d_desc, d_sad, d_mv, d_center=None,
-                              d_state=None, stream=None, l0_mv_stride=1):
-    """Fused search-centre chain + 85-PU full-pel search for len(curs) picture pairs (see hme_search_center_batch_dev)."""
-    n = len(curs)
-    ca = (PaPictureDesc * n)(*curs)
-    ra = (PaPictureDesc * n)(*refs)
-    _check(lib().svthip_me_integer_search_batch_dev(self._h, d_pool, ca, ra, n, C.byref(params), list_index, d_sb, n_sb, d_l0_mv64,
-                                                    l0_mv_stride, d_desc, d_center, d_state, d_sad, d_mv, stream))
-
-
 def _motion_estimate_picture_dev(self, d_pool, cur, ref0, ref1, params, d_sb, n_sb, d_out, use_subpel=True, cu8x8_mode=0,
                                  d_list_sad=None, d_list_mv=None, stream=None):
     """Whole-picture ME (MotionEstimateLcu over all SBs): ref1=None for P pictures."""
@@ -248,7 +234,6 @@ def _fullpel_search209_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n
 Context.fullpel_search209_dev = _fullpel_search209_dev
 Context.hme_search_center_dev = _hme_search_center_dev
 Context.hme_search_center_batch_dev = _hme_search_center_batch_dev
-Context.integer_search_batch_dev = _integer_search_batch_dev
 
 
 def _subpel_refine_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv, disable_8x8=False,

@@ -161,34 +161,3 @@ def test_batched_launch_equals_per_picture_launches(hip_ctx):
     hip_ctx.synchronize()
     assert torch.equal(d_one, d_bat) and torch.equal(d_cen1, d_cen2)
     assert (d_cen2 != 0).any()
-
-
-@pytest.mark.parametrize("shape", [(320, 192), (856, 480)])
-def test_fused_integer_search_equals_separate_calls(hip_ctx, shape):
-    """svthip_me_integer_search_batch_dev == search-centre batch + full-pel search on its descriptors (incl. partial SBs)."""
-    import torch
-
-    w, h = shape
-    n_pic = 3
-    pics = [synth.PaPicture(synth.synth_luma(w, h, 2 * i)) for i in range(n_pic + 1)]
-    pool, pd = svtav1_hip.build_picture_pool(pics)
-    d_pool = torch.from_numpy(pool).to("cuda:0")
-    sbs = svtav1_hip.sb_origins(w, h)
-    n_sb = sbs.shape[0]
-    d_sb = torch.from_numpy(sbs.view(np.int16).copy()).to("cuda:0")
-    params = svtav1_hip.default_me_params(w, h, 3, 0)
-    curs, refs = [pd[i + 1] for i in range(n_pic)], [pd[i] for i in range(n_pic)]
-    n = n_pic * n_sb
-    d_desc1 = torch.zeros((n, 6), dtype=torch.int32, device="cuda:0")
-    d_sad1 = torch.zeros((n, 85), dtype=torch.int32, device="cuda:0"); d_mv1 = torch.zeros_like(d_sad1)
-    hip_ctx.hme_search_center_batch_dev(d_pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_sb, None, d_desc1.data_ptr())
-    stride = pd[0].full_stride
-    hip_ctx.fullpel_search_dev(d_pool.data_ptr(), stride, d_pool.data_ptr(), stride, d_desc1.data_ptr(), n, params.search_area_width,
-                               params.search_area_height, d_sad1.data_ptr(), d_mv1.data_ptr())
-    d_desc2 = torch.zeros((n, 6), dtype=torch.int32, device="cuda:0")
-    d_sad2 = torch.full((n, 85), -1, dtype=torch.int32, device="cuda:0"); d_mv2 = torch.full((n, 85), -1, dtype=torch.int32, device="cuda:0")
-    hip_ctx.integer_search_batch_dev(d_pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_sb, None, d_desc2.data_ptr(),
-                                     d_sad2.data_ptr(), d_mv2.data_ptr())
-    hip_ctx.synchronize()
-    assert torch.equal(d_desc1, d_desc2)
-    assert torch.equal(d_sad1, d_sad2) and torch.equal(d_mv1, d_mv2)
