@@ -300,6 +300,28 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
     return out
 
 
+def leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev):
+    """configs[2] (8-tap half): av1_convolve_2d_sr on 64x64 blocks of one 1080p frame at all 15 x 15 fractional phases
+    (SURVEY 8d config 3): 510 blocks x 225 phases = 114 750 blocks per launch, filters cycling REGULAR / SMOOTH / SHARP / BILINEAR."""
+    S = pdesc[0].full_stride
+    nbx, nby, n_ph = 30, 17, 225
+    n = nbx * nby * n_ph
+    d = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    i = np.arange(n)
+    blk, ph = i // n_ph, i % n_ph
+    d["src_offset"] = pdesc[1].full_offset + (68 + (blk // nbx) * 64) * S + 68 + (blk % nbx) * 64
+    d["dst_offset"] = i * 4096                       # dense 64 x 64 tiles
+    d["subpel_x"], d["subpel_y"] = 1 + ph % 15, 1 + ph // 15
+    d["filter_x"], d["filter_y"] = (blk + ph) % 4, (blk // 3 + ph // 5) % 4
+    d_desc = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_dst = torch.empty(n * 4096, dtype=torch.uint8, device=dev)
+    ms = timer.ms(lambda: ctx.av1_convolve_sr_batch_dev(pool.data_ptr(), S, d_dst.data_ptr(), 64, d_desc.data_ptr(), n, 64, 64, timer.stream), 10)
+    algo = n * (71 * 71 + 4096 + 16)
+    return {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
+            "frac_hbm": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per block"}
+
+
 def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):
     """configs[4] on one GPU: 3840x2160 -- hierarchical ME on the 8-bit MSB plane (2040 SBs per picture) and the 10-bit fused TU chain
     (svthip_encode_tu16_batch_dev, bd 10 rows) over one 4K luma frame."""
@@ -557,6 +579,7 @@ def main():
             d_sb_all = torch.from_numpy(sb_all.view(np.int16).copy()).to(dev)
             params_b = svtav1_hip.default_me_params(W, H, 3, 1)
             legs["me_chain_subpel"] = leg_me_chain(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
+            legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
             legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
             legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)
 

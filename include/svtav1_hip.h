@@ -429,6 +429,32 @@ int32_t svthip_pad_plane_dev(svthip_ctx *ctx, void *d_plane, uint32_t stride, ui
                              uint32_t pad_height, uint32_t sample_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * AV1 inter prediction: 8-bit single-reference convolutions of a batch of blocks of ONE size.
+ * Per block, what av1_inter_prediction does for one plane of a uni-predicted block (Codec/EbInterPrediction.c:1255-1287):
+ * convolve[subpel_x != 0][subpel_y != 0][0] = av1_convolve_2d_sr / av1_convolve_x_sr / av1_convolve_y_sr / av1_convolve_2d_copy_sr
+ * (C bodies :145-286, RTCD Codec/aom_dsp_rtcd.h:2067-2076) with filter kernels chosen by
+ * av1_get_interp_filter_params_with_block_size (:985-995: blocks <= 4 samples wide / high use the 4-tap tables) and
+ * get_conv_params_no_round(.., is_compound = 0, EB_8BIT) rounding (round_0 = 3, round_1 = 11).
+ *
+ * d_src / d_dst : uint8 planes.  Block i reads around d_src + src_offset (the block's top-left sample AFTER the integer part of the
+ *                 motion vector has been applied: srcPtr + (mv_q4.row >> 4) * stride + (mv_q4.col >> 4), :1265) -- 3 samples
+ *                 left / above and 4 right / below when the respective phase is non-zero -- and writes width x height samples at
+ *                 d_dst + dst_offset.  The source plane must stay readable 16 bytes past the last sample a block needs.
+ * subpel_x / subpel_y : mv_q4 & SUBPEL_MASK, 0..15 (1/16 sample).
+ * filter_x / filter_y : InterpFilter of each direction: 0 EIGHTTAP_REGULAR, 1 EIGHTTAP_SMOOTH, 2 MULTITAP_SHARP, 3 BILINEAR
+ *                 (av1_extract_interp_filter(interp_filters, 1 / 0)).
+ * width x height : one of the 22 AV1 block sizes (4..128, aspect <= 4:1; the host groups blocks by size). */
+typedef struct svthip_convolve_desc {
+    uint32_t src_offset;
+    uint32_t dst_offset;
+    uint8_t subpel_x, subpel_y, filter_x, filter_y;
+    uint32_t reserved;
+} svthip_convolve_desc;
+
+int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, uint32_t src_stride, uint8_t *d_dst, uint32_t dst_stride,
+                                         const svthip_convolve_desc *d_desc, uint32_t n_blocks, uint32_t width, uint32_t height, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Reference-layout results and host-pointer forms (what a C host that owns host memory binds).
  *
  * svthip_me_cu_result_ref has the memory layout of the reference's MeCuResults_t (Codec/EbMotionEstimationLcuResults.h:56-76) as

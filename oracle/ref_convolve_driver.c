@@ -1,0 +1,31 @@
+/*
+ * oracle/ref_convolve_driver.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Calls the REFERENCE's own 8-bit single-reference convolutions (compiled from /root/reference into oracle/_ref/libsvtref_me.so)
+ * the way av1_inter_prediction does for the luma plane of a uni-predicted block (Codec/EbInterPrediction.c:1255-1287):
+ * filter parameters from av1_get_interp_filter_params_with_block_size, conv params from get_conv_params_no_round(.., 0, EB_8BIT),
+ * dispatch on (subpel_x != 0, subpel_y != 0).  Contains no reference code, only calls into it.
+ */
+#include <stdint.h>
+
+#include "EbDefinitions.h"
+#include "convolve.h"
+
+InterpFilterParams av1_get_interp_filter_params_with_block_size(const InterpFilter interp_filter, const int32_t w);
+#define DECL(n)                                                                                                                          \
+    void n(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, int32_t w, int32_t h, InterpFilterParams *filter_params_x, \
+           InterpFilterParams *filter_params_y, const int32_t subpel_x_q4, const int32_t subpel_y_q4, ConvolveParams *conv_params);
+DECL(av1_convolve_2d_sr_c) DECL(av1_convolve_x_sr_c) DECL(av1_convolve_y_sr_c) DECL(av1_convolve_2d_copy_sr_c)
+
+void ref_av1_convolve_sr(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, int32_t w, int32_t h, int filter_x,
+                         int filter_y, int subpel_x, int subpel_y)
+{
+    uint16_t tmp[128 * 128];
+    ConvolveParams cp = get_conv_params_no_round(0, 0, 0, tmp, 128, 0, EB_8BIT);
+    InterpFilterParams px = av1_get_interp_filter_params_with_block_size((InterpFilter)filter_x, w);
+    InterpFilterParams py = av1_get_interp_filter_params_with_block_size((InterpFilter)filter_y, h);
+    if (subpel_x && subpel_y) av1_convolve_2d_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
+    else if (subpel_y) av1_convolve_y_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
+    else if (subpel_x) av1_convolve_x_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
+    else av1_convolve_2d_copy_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
+}

@@ -1,0 +1,83 @@
+/*
+ * oracle/svt_interp_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see svt_me_oracle.h).
+ *
+ * Plain-C restatement of the 8-bit single-reference AV1 inter-prediction convolutions, paths under
+ * Source/Lib/Codec of the reference:
+ *   av1_convolve_2d_sr_c       EbInterPrediction.c:145-198   horizontal 8-tap -> int16 (round_0 = 3, offset 1 << 14), vertical 8-tap
+ *                                                            (round_1 = 11, offset 1 << 19 removed again), clip
+ *   av1_convolve_y_sr_c        :200-232                      vertical only, (sum + 64) >> 7
+ *   av1_convolve_x_sr_c        :234-267                      horizontal only, ((sum + 4) >> 3 + 8) >> 4  (two roundings)
+ *   av1_convolve_2d_copy_sr_c  :269-286
+ *   dispatch convolve[subpel_x != 0][subpel_y != 0][0]       :898-911, call site :1276-1287
+ *   filter choice av1_get_interp_filter_params_with_block_size :985-995 (4-tap kernels for blocks <= 4 wide / high)
+ *   conv params get_conv_params_no_round(.., is_compound = 0, bd = 8): round_0 = 3, round_1 = 11 (convolve.h:115-143)
+ * PINNED against the reference's own functions (oracle/ref_convolve_driver.c) in tests/test_convolve_vs_ref.py for every filter,
+ * every phase pair and every AV1 block size.
+ */
+#include <stdint.h>
+
+static const int16_t kFilters[6][16][8] =
+#include "svt_interp_filters.inc"
+    ;
+
+static inline uint8_t clip8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* index into kFilters for InterpFilter `f` (0 regular, 1 smooth, 2 sharp, 3 bilinear) on a dimension of `size` samples */
+static int filter_index(int f, int size)
+{
+    if (size <= 4 && (f == 2 || f == 0)) return 4;
+    if (size <= 4 && f == 1) return 5;
+    return f;
+}
+
+void orc_av1_convolve_sr(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, int32_t w, int32_t h, int filter_x,
+                         int filter_y, int subpel_x, int subpel_y)
+{
+    const int16_t *fx = kFilters[filter_index(filter_x, w)][subpel_x & 15], *fy = kFilters[filter_index(filter_y, h)][subpel_y & 15];
+    if (subpel_x && subpel_y) {
+        static int16_t im[(128 + 7) * 128];
+        const int im_h = h + 7;
+        const uint8_t *s = src - 3 * src_stride;
+        for (int y = 0; y < im_h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << 14; /* 1 << (bd + FILTER_BITS - 1) */
+                for (int k = 0; k < 8; k++) sum += fx[k] * s[y * src_stride + x - 3 + k];
+                im[y * w + x] = (int16_t)((sum + 4) >> 3);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << 19; /* offset_bits = bd + 2 * FILTER_BITS - round_0 */
+                for (int k = 0; k < 8; k++) sum += fy[k] * im[(y + k) * w + x];
+                const int16_t res = (int16_t)(uint16_t)(((sum + (1 << 10)) >> 11) - ((1 << 8) + (1 << 7)));
+                dst[y * dst_stride + x] = clip8(res); /* bits = 0 */
+            }
+    } else if (subpel_y) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t res = 0;
+                for (int k = 0; k < 8; k++) res += fy[k] * src[(y - 3 + k) * src_stride + x];
+                dst[y * dst_stride + x] = clip8((res + 64) >> 7);
+            }
+    } else if (subpel_x) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t res = 0;
+                for (int k = 0; k < 8; k++) res += fx[k] * src[y * src_stride + x - 3 + k];
+                res = (res + 4) >> 3;
+                dst[y * dst_stride + x] = clip8((res + 8) >> 4);
+            }
+    } else {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) dst[y * dst_stride + x] = src[y * src_stride + x];
+    }
+}
+
+/* the batch the device entry takes: desc = { src_offset, dst_offset, subpel_x | subpel_y << 8 | filter_x << 16 | filter_y << 24, 0 } */
+void orc_av1_convolve_sr_batch(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, const uint32_t *desc, uint32_t n,
+                               int32_t w, int32_t h)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *d = desc + 4 * i;
+        orc_av1_convolve_sr(src + d[0], src_stride, dst + d[1], dst_stride, w, h, (d[2] >> 16) & 255, (d[2] >> 24) & 255, d[2] & 255, (d[2] >> 8) & 255);
+    }
+}

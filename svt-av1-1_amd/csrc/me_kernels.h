@@ -92,6 +92,10 @@ __global__ void fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_
                                   uint32_t* __restrict__ out_mv);
 size_t fullpel209_lds_bytes(uint32_t max_sh);
 
+bool convolve_size_valid(int w, int h);
+hipError_t launch_av1_convolve_sr(const uint8_t* src, uint32_t src_stride, uint8_t* dst, uint32_t dst_stride, const svthip_convolve_desc* desc,
+                                  uint32_t n_blocks, int w, int h, hipStream_t s);
+
 inline size_t fullpel_lds_bytes(uint32_t max_sh) { return SVTHIP_FULLPEL_LDS_FIXED + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }
 
 }  // namespace svthip

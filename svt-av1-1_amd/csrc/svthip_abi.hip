@@ -682,6 +682,20 @@ int32_t svthip_pad_plane_dev(svthip_ctx* ctx, void* d_plane, uint32_t stride, ui
     return SVTHIP_OK;
 }
 
+int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_stride, uint8_t* d_dst, uint32_t dst_stride,
+                                         const svthip_convolve_desc* d_desc, uint32_t n_blocks, uint32_t width, uint32_t height, void* stream)
+{
+    ENTER(ctx);
+    if (!svthip::convolve_size_valid((int)width, (int)height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "not an AV1 block size%s (width %d)", "", (int)width);
+    if (n_blocks == 0) return SVTHIP_OK;
+    if (!d_src || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (reinterpret_cast<uintptr_t>(d_desc) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(svthip::launch_av1_convolve_sr(d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_results_to_ref_layout_dev(svthip_ctx* ctx, const svthip_me_cu_result* d_in, uint32_t n, svthip_me_cu_result_ref* d_out,
                                             void* stream)
 {

@@ -116,6 +116,9 @@ def lib() -> C.CDLL:
     L.svthip_pa_derive_planes_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]
     L.svthip_pad_plane_dev.restype = C.c_int32
     L.svthip_pad_plane_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.svthip_av1_convolve_sr_batch_dev.restype = C.c_int32
+    L.svthip_av1_convolve_sr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                   C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -329,6 +332,22 @@ def _pad_plane_dev(self, d_plane, stride, width, height, pad_w, pad_h, sample_by
 
 Context.pa_derive_planes_dev = _pa_derive_planes_dev
 Context.pad_plane_dev = _pad_plane_dev
+
+
+CONVOLVE_DESC_DTYPE = np.dtype([("src_offset", "<u4"), ("dst_offset", "<u4"), ("subpel_x", "u1"), ("subpel_y", "u1"), ("filter_x", "u1"),
+                                ("filter_y", "u1"), ("reserved", "<u4")])
+assert CONVOLVE_DESC_DTYPE.itemsize == 16
+# the 22 AV1 block sizes (width, height)
+AV1_BLOCK_SIZES_WH = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64),
+                      (64, 128), (128, 64), (128, 128), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+def _av1_convolve_sr_batch_dev(self, d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, width, height, stream=None):
+    """8-bit single-reference AV1 convolution (2-D / x / y / copy by phase) of n_blocks blocks of one size."""
+    _check(lib().svthip_av1_convolve_sr_batch_dev(self._h, d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, width, height, stream))
+
+
+Context.av1_convolve_sr_batch_dev = _av1_convolve_sr_batch_dev
 
 
 def make_fullpel_desc(cur, ref, centers=None, search_w=64, search_h=64) -> np.ndarray:

@@ -1,0 +1,119 @@
+"""GPU parity: svthip_av1_convolve_sr_batch_dev (AV1 8-tap / 4-tap single-reference inter prediction, 8-bit) vs the oracle, which
+tests/test_convolve_vs_ref.py pins against the reference's av1_convolve_*_sr_c.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import svtav1_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_batch(oracle, src, S, dst, D, desc, w, h):
+    f = oracle.lib.orc_av1_convolve_sr_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]
+    d = np.zeros((len(desc), 4), np.uint32)
+    d[:, 0], d[:, 1] = desc["src_offset"], desc["dst_offset"]
+    d[:, 2] = desc["subpel_x"].astype(np.uint32) | (desc["subpel_y"].astype(np.uint32) << 8) | (desc["filter_x"].astype(np.uint32) << 16) | \
+        (desc["filter_y"].astype(np.uint32) << 24)
+    f(src.ctypes.data, S, dst.ctypes.data, D, d.ctypes.data, len(desc), w, h)
+
+
+def _run(hip_ctx, src, S, dst, D, desc, w, h):
+    import torch
+    d_src = torch.from_numpy(np.concatenate([src.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d_dst = torch.from_numpy(dst.reshape(-1).copy()).to("cuda:0")
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    hip_ctx.av1_convolve_sr_batch_dev(d_src.data_ptr(), S, d_dst.data_ptr(), D, d_desc.data_ptr(), len(desc), w, h)
+    hip_ctx.synchronize()
+    return d_dst.cpu().numpy().reshape(dst.shape)
+
+
+@pytest.mark.parametrize("size", svtav1_hip.AV1_BLOCK_SIZES_WH)
+def test_convolve_every_block_size(hip_ctx, oracle, size):
+    pytest.importorskip("torch")
+    w, h = size
+    rng = np.random.default_rng(w * 257 + h)
+    S, R = 640, 400
+    src = rng.integers(0, 256, (R, S), dtype=np.uint8)
+    src[:40] = (((np.arange(S)[None, :] // 2 + np.arange(40)[:, None] // 3) & 1) * 255).astype(np.uint8)   # both clips
+    cols, rows = 512 // w, 256 // h
+    n = min(cols * rows, 300) - 1     # not a multiple of the blocks-per-workgroup group: ragged last workgroup
+    slots = rng.permutation(cols * rows)[:n]
+    D = 512 + 3                        # odd destination stride: byte-granular stores
+    dst = np.full((256, D), 0x55, np.uint8)
+    desc = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    for i, sl in enumerate(slots):
+        bx, by = (int(sl) % cols) * w, (int(sl) // cols) * h
+        mvx, mvy = int(rng.integers(-20, 21)), int(rng.integers(-20, 21))
+        sx = min(max(40 + bx + mvx, 8), S - w - 8); sy = min(max(40 + by + mvy, 8), R - h - 8)
+        desc[i] = (sy * S + sx, by * D + bx, int(rng.integers(0, 16)), int(rng.integers(0, 16)), int(rng.integers(0, 4)), int(rng.integers(0, 4)), 0)
+    desc["subpel_x"][:6] = [0, 0, 5, 0, 15, 8]; desc["subpel_y"][:6] = [0, 7, 0, 0, 15, 8]   # copy / y-only / x-only / 2-D all present
+    want = dst.copy()
+    _oracle_batch(oracle, src, S, want, D, desc, w, h)
+    got = _run(hip_ctx, src, S, dst, D, desc, w, h)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (size, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
+def test_convolve_64x64_all_phases_1080p(hip_ctx, oracle):
+    """64x64 blocks at all 15 x 15 fractional phases -- here all 16 x 16 (the zero phases take the x-only / y-only /
+    copy functions) over one 1080p frame: 510 blocks x 256 phase pairs, one launch.  Oracle on a sample; properties over everything:
+    phase (0,0) is a copy, bilinear at phase 8 in x only is the rounded average of horizontal neighbours."""
+    torch = pytest.importorskip("torch")
+    from svtav1_hip import synth
+    pic = synth.PaPicture(synth.synth_luma(1920, 1088, 1))
+    S = pic.stride
+    src = pic.full
+    nbx, nby = 30, 17
+    n_ph = 256
+    desc = np.zeros(nbx * nby * n_ph, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    i = np.arange(desc.size)
+    blk, ph = i // n_ph, i % n_ph
+    bx, by = (blk % nbx) * 64, (blk // nbx) * 64
+    desc["src_offset"] = (68 + by) * S + 68 + bx
+    D = 64 * n_ph                                   # destination: one row of 64 x 64 tiles per block, one tile per phase
+    desc["dst_offset"] = blk * (64 * D) + ph * 64
+    desc["subpel_x"], desc["subpel_y"] = ph % 16, ph // 16
+    desc["filter_x"] = (blk + ph) % 4
+    desc["filter_y"] = (blk // 3 + ph // 5) % 4
+    d_src = torch.from_numpy(np.concatenate([src.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d_dst = torch.zeros(nbx * nby * 64 * D, dtype=torch.uint8, device="cuda:0")
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    hip_ctx.av1_convolve_sr_batch_dev(d_src.data_ptr(), S, d_dst.data_ptr(), D, d_desc.data_ptr(), desc.size, 64, 64)
+    hip_ctx.synchronize()
+    got = d_dst.cpu().numpy().reshape(nbx * nby * 64, D)
+    rng = np.random.default_rng(1)
+    pick = rng.choice(desc.size, 400, replace=False)
+    f = oracle.lib.orc_av1_convolve_sr
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    for k in pick:
+        d = desc[k]
+        tile = np.zeros((64, 64), np.uint8)
+        f(src.ctypes.data + int(d["src_offset"]), S, tile.ctypes.data, 64, 64, 64, int(d["filter_x"]), int(d["filter_y"]), int(d["subpel_x"]),
+          int(d["subpel_y"]))
+        b, p = int(k) // n_ph, int(k) % n_ph
+        assert np.array_equal(got[b * 64:(b + 1) * 64, p * 64:(p + 1) * 64], tile), (b, p)
+    for b in range(0, nbx * nby, 7):
+        x0, y0 = (b % nbx) * 64, (b // nbx) * 64
+        blk_src = src[68 + y0:68 + y0 + 64, 68 + x0:68 + x0 + 64 + 1].astype(np.int32)
+        assert np.array_equal(got[b * 64:(b + 1) * 64, 0:64], blk_src[:, :64])                 # phase (0,0): copy
+        d8 = desc[b * n_ph + 8]
+        if d8["filter_x"] == 3:                                                                  # bilinear, x phase 8, y phase 0
+            avg = (((64 * blk_src[:, :64] + 64 * blk_src[:, 1:65] + 4) >> 3) + 8) >> 4
+            assert np.array_equal(got[b * 64:(b + 1) * 64, 8 * 64:9 * 64], avg)
+
+
+def test_convolve_rejects_bad_arguments(hip_ctx):
+    torch = pytest.importorskip("torch")
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.av1_convolve_sr_batch_dev(buf.data_ptr(), 256, buf.data_ptr(), 256, buf.data_ptr(), 1, 12, 12)    # not a block size
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.av1_convolve_sr_batch_dev(buf.data_ptr(), 256, buf.data_ptr(), 256, buf.data_ptr(), 1, 4, 32)     # 8:1
+    with pytest.raises(svtav1_hip.SvtHipError):
+        hip_ctx.av1_convolve_sr_batch_dev(buf.data_ptr(), 256, buf.data_ptr(), 256, buf.data_ptr() + 4, 1, 8, 8)  # misaligned descriptors

@@ -1,0 +1,77 @@
+"""Pins the AV1 single-reference convolution oracle (oracle/svt_interp_oracle.c) and its filter tables against the reference's own
+av1_convolve_2d_sr_c / _x_sr_c / _y_sr_c / _2d_copy_sr_c driven like av1_inter_prediction (oracle/ref_convolve_driver.c): every
+interpolation filter, all 16 x 16 phase pairs, every AV1 block size.  CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+ME_SO = os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so")
+
+# the 22 AV1 block sizes (width, height)
+BLOCK_SIZES = [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (16, 16), (16, 32), (32, 16), (32, 32), (32, 64), (64, 32), (64, 64), (64, 128),
+               (128, 64), (128, 128), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16)]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(ME_SO):
+        pytest.skip("oracle/_ref not built")
+    lib = C.CDLL(ME_SO, mode=os.RTLD_LAZY)
+    lib.ref_av1_convolve_sr.restype = None
+    lib.ref_av1_convolve_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    return lib
+
+
+def _orc(oracle):
+    f = oracle.lib.orc_av1_convolve_sr
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    return f
+
+
+@pytest.mark.parametrize("filters", [(0, 0), (1, 1), (2, 2), (3, 3), (0, 2), (1, 0)])
+def test_every_phase_pair_matches_reference(oracle, ref, filters):
+    fx, fy = filters
+    orc = _orc(oracle)
+    rng = np.random.default_rng(fx * 4 + fy)
+    for (w, h) in ((64, 64), (4, 4), (8, 16)):
+        S = w + 16
+        src = rng.integers(0, 256, (h + 16, S), dtype=np.uint8)
+        src[:4] = 255; src[4:8, ::2] = 0   # extremes: both clips
+        for sx in range(16):
+            for sy in range(16):
+                a = np.full((h, w), 7, np.uint8); b = np.full((h, w), 9, np.uint8)
+                p = src.ctypes.data + 8 * S + 8
+                ref.ref_av1_convolve_sr(p, S, a.ctypes.data, w, w, h, fx, fy, sx, sy)
+                orc(p, S, b.ctypes.data, w, w, h, fx, fy, sx, sy)
+                assert np.array_equal(a, b), (w, h, fx, fy, sx, sy)
+
+
+@pytest.mark.parametrize("size", BLOCK_SIZES)
+def test_every_block_size_matches_reference(oracle, ref, size):
+    w, h = size
+    orc = _orc(oracle)
+    rng = np.random.default_rng(w * 131 + h)
+    S = w + 24
+    for kind in range(3):
+        if kind == 0:
+            src = rng.integers(0, 256, (h + 16, S), dtype=np.uint8)
+        elif kind == 1:
+            yy, xx = np.mgrid[0:h + 16, 0:S]
+            src = (((xx // 2 + yy // 3) & 1) * 255).astype(np.uint8)
+        else:
+            src = np.clip(128 + 90 * np.sin(np.arange(S) / 3.0)[None, :] + rng.normal(0, 8, (h + 16, S)), 0, 255).astype(np.uint8)
+        for trial in range(12):
+            fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            sx, sy = int(rng.integers(0, 16)), int(rng.integers(0, 16))
+            if trial < 3:
+                sx = 0 if trial != 1 else sx
+                sy = 0 if trial != 2 else sy
+            a = np.zeros((h, w + 5), np.uint8); b = np.zeros((h, w + 5), np.uint8)
+            p = src.ctypes.data + 8 * S + 8
+            ref.ref_av1_convolve_sr(p, S, a.ctypes.data, w + 5, w, h, fx, fy, sx, sy)
+            orc(p, S, b.ctypes.data, w + 5, w, h, fx, fy, sx, sy)
+            assert np.array_equal(a, b), (w, h, fx, fy, sx, sy)
