@@ -322,6 +322,30 @@ def leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev):
             "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per block"}
 
 
+def leg_sad_loop(ctx, torch, svtav1_hip, timer, dev):
+    """configs[0] on the GPU: SadLoopKernel semantics, every 16x16 block of 12 synthetic 856x480 pictures (53 x 30 = 1590 per picture),
+    +-16 search = 33 x 33 positions, full rows."""
+    w, h, n_pic = 856, 480, 12
+    pool, descs = device_picture_pool(ctx, n_pic + 1, w, h, dev)
+    S = descs[0].full_stride
+    rows = []
+    for j in range(n_pic):
+        for by in range(0, 480, 16):
+            for bx in range(0, 848, 16):
+                rows.append((descs[j + 1].full_offset + (68 + by) * S + 68 + bx, descs[j].full_offset + (68 + by - 16) * S + 68 + bx - 16))
+    d = np.asarray(rows, dtype=np.uint32)
+    n = d.shape[0]
+    d_desc = torch.from_numpy(d.view(np.int32).reshape(-1).copy()).to(dev)
+    d_sad = torch.empty(n, dtype=torch.int32, device=dev)
+    d_xy = torch.empty((n, 2), dtype=torch.int16, device=dev)
+    ms = timer.ms(lambda: ctx.sad_loop_batch_dev(pool.data_ptr(), S, pool.data_ptr(), S, S, d_desc.data_ptr(), n, 16, 16, 33, 33, d_sad.data_ptr(),
+                                                 d_xy.data_ptr(), timer.stream), 10)
+    absdiff = n * 33 * 33 * 256
+    return {"blocks": n, "ms": round(ms, 4), "blocks_per_s": round(n / ms * 1e3, 0), "absdiff_per_s": round(absdiff / ms * 1e3, 0),
+            "frac_sad_ceiling": round(absdiff / ms * 1e3 / VALU_PEAK_ABSDIFF_PER_S, 4),
+            "workload": "16x16 blocks, 33x33 positions (+-16), 856x480 8-bit, 12 pictures per launch, SadLoopKernel semantics (generic kernel, v_sad_u8)"}
+
+
 def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):
     """configs[4] on one GPU: 3840x2160 -- hierarchical ME on the 8-bit MSB plane (2040 SBs per picture) and the 10-bit fused TU chain
     (svthip_encode_tu16_batch_dev, bd 10 rows) over one 4K luma frame."""
@@ -579,6 +603,7 @@ def main():
             d_sb_all = torch.from_numpy(sb_all.view(np.int16).copy()).to(dev)
             params_b = svtav1_hip.default_me_params(W, H, 3, 1)
             legs["me_chain_subpel"] = leg_me_chain(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
+            legs["sad_loop_480p"] = leg_sad_loop(ctx, torch, svtav1_hip, timer, dev)
             legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
             legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
             legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)

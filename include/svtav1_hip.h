@@ -429,6 +429,26 @@ int32_t svthip_pad_plane_dev(svthip_ctx *ctx, void *d_plane, uint32_t stride, ui
                              uint32_t pad_height, uint32_t sample_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * SadLoopKernel for a batch of blocks: NxMSadLoopKernel_funcPtrArray[asm_type] (Codec/EbComputeSAD.h:183-189) = SadLoopKernel
+ * (C_DEFAULT/EbComputeSAD_C.c:73-119; signature EB_SADLOOPKERNELNxM_TYPE, Codec/EbComputeSAD.h:38-51) with the reference's full
+ * argument set, for n_blocks blocks per launch.  Block i: source block at d_src + src_offset (rows src_stride apart), search grid
+ * origin at d_ref + ref_offset; candidate (x, y), 0 <= x < search_area_width, 0 <= y < search_area_height, compares block row r with
+ * reference row y * ref_stride_raw + r * ref_stride at column x.  ref_stride must be ref_stride_raw or 2 * ref_stride_raw (the HME
+ * callers skip every other row, Codec/EbMotionEstimation.c:4453-4470).  Result = the first minimum in raster order (strict '<' from
+ * 0xffffff): d_best_sad[i] (the reference's *bestSad), d_best_xy[2 i] = xSearchCenter index, [2 i + 1] = ySearchCenter index.
+ * width: multiple of 4, 4..64; height 1..64; search_area_width * search_area_height <= 4096; the per-block window must fit the LDS
+ * slice (SVTHIP_ERR_BAD_PARAMETER otherwise).  BASELINE configs[0] = 16x16 blocks, 33x33 positions at 856x480. */
+typedef struct svthip_sad_loop_desc {
+    uint32_t src_offset;
+    uint32_t ref_offset;
+} svthip_sad_loop_desc;
+
+int32_t svthip_sad_loop_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, uint32_t src_stride, const uint8_t *d_ref, uint32_t ref_stride,
+                                  uint32_t ref_stride_raw, const svthip_sad_loop_desc *d_desc, uint32_t n_blocks, uint32_t width,
+                                  uint32_t height, uint32_t search_area_width, uint32_t search_area_height, uint32_t *d_best_sad,
+                                  int16_t *d_best_xy, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * AV1 inter prediction: 8-bit single-reference convolutions of a batch of blocks of ONE size.
  * Per block, what av1_inter_prediction does for one plane of a uni-predicted block (Codec/EbInterPrediction.c:1255-1287):
  * convolve[subpel_x != 0][subpel_y != 0][0] = av1_convolve_2d_sr / av1_convolve_x_sr / av1_convolve_y_sr / av1_convolve_2d_copy_sr

@@ -682,6 +682,29 @@ int32_t svthip_pad_plane_dev(svthip_ctx* ctx, void* d_plane, uint32_t stride, ui
     return SVTHIP_OK;
 }
 
+int32_t svthip_sad_loop_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_stride, const uint8_t* d_ref, uint32_t ref_stride,
+                                  uint32_t ref_stride_raw, const svthip_sad_loop_desc* d_desc, uint32_t n_blocks, uint32_t width, uint32_t height,
+                                  uint32_t search_area_width, uint32_t search_area_height, uint32_t* d_best_sad, int16_t* d_best_xy, void* stream)
+{
+    ENTER(ctx);
+    if (width < 4 || width > 64 || (width & 3u) || height < 1 || height > 64)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "block must be 4..64 wide (multiple of 4) and 1..64 high%s (width %d)", "", (int)width);
+    if (!search_area_width || !search_area_height || search_area_width * search_area_height > 4096u)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must hold 1..4096 positions%s (width %d)", "", (int)search_area_width);
+    if (!ref_stride_raw || (ref_stride != ref_stride_raw && ref_stride != 2 * ref_stride_raw))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "ref_stride must be ref_stride_raw or twice it%s (got %d)", "", (int)ref_stride);
+    if (n_blocks == 0) return SVTHIP_OK;
+    if (!d_src || !d_ref || !d_desc || !d_best_sad || !d_best_xy) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    const size_t slice = svthip::sad_loop_slice_bytes((int)width, (int)height, (int)search_area_width, (int)search_area_height,
+                                                      (int)(ref_stride / ref_stride_raw));
+    if (slice * 4 > 64 * 1024) return fail(SVTHIP_ERR_BAD_PARAMETER, "block + search window too large for the LDS slice%s (%d bytes)", "", (int)slice);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipLaunchKernelGGL(svthip::sad_loop_kernel, dim3((n_blocks + 3) / 4), dim3(256), slice * 4, s, d_src, src_stride, d_ref, ref_stride, ref_stride_raw,
+                       d_desc, n_blocks, (int)width, (int)height, (int)search_area_width, (int)search_area_height, (int)slice, d_best_sad, d_best_xy);
+    HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
 int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_stride, uint8_t* d_dst, uint32_t dst_stride,
                                          const svthip_convolve_desc* d_desc, uint32_t n_blocks, uint32_t width, uint32_t height, void* stream)
 {

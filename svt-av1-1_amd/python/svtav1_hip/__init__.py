@@ -119,6 +119,9 @@ def lib() -> C.CDLL:
     L.svthip_av1_convolve_sr_batch_dev.restype = C.c_int32
     L.svthip_av1_convolve_sr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                                    C.c_uint32, C.c_void_p]
+    L.svthip_sad_loop_batch_dev.restype = C.c_int32
+    L.svthip_sad_loop_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -332,6 +335,16 @@ def _pad_plane_dev(self, d_plane, stride, width, height, pad_w, pad_h, sample_by
 
 Context.pa_derive_planes_dev = _pa_derive_planes_dev
 Context.pad_plane_dev = _pad_plane_dev
+
+
+def _sad_loop_batch_dev(self, d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, width, height, sw, sh, d_best_sad, d_best_xy,
+                        stream=None):
+    """SadLoopKernel over n_blocks (src_offset, ref_offset) uint32 pairs; d_best_sad uint32 [n], d_best_xy int16 [n][2] = (x, y) index."""
+    _check(lib().svthip_sad_loop_batch_dev(self._h, d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, width, height, sw, sh,
+                                           d_best_sad, d_best_xy, stream))
+
+
+Context.sad_loop_batch_dev = _sad_loop_batch_dev
 
 
 CONVOLVE_DESC_DTYPE = np.dtype([("src_offset", "<u4"), ("dst_offset", "<u4"), ("subpel_x", "u1"), ("subpel_y", "u1"), ("filter_x", "u1"),
