@@ -475,6 +475,46 @@ int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, 
                                          const svthip_convolve_desc *d_desc, uint32_t n_blocks, uint32_t width, uint32_t height, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batching layer for the transform / quantisation callers.  The reference calls its T/Q kernels one TU and one
+ * transform type at a time from ProductFullLoopTxSearch (Codec/EbFullLoop.c:1138-1352: for every tx_type candidate of a TU:
+ * Av1EstimateTransform -> Av1QuantizeInvQuantize -> distortion -> cost), encode_pass_tx_search (:1354-1550) and Av1EncodeLoop
+ * (Codec/EbCodingLoop.c:552-913).  A batcher is the host-side gather / scatter that lets those callers keep their control flow:
+ * they ADD every (TU, tx_type) candidate they would have evaluated, FLUSH once (descriptors are grouped by transform size, one
+ * fused-chain launch per size present -- svthip_encode_tu[16]_batch_dev), and READ each candidate's eob / energy / distortion (and,
+ * when wanted, its quantised levels) back by handle to make the same decision the serial loop makes.
+ *
+ * One batcher belongs to one context (one thread).  Planes and tables are DEVICE buffers bound with _begin (the picture's source
+ * plane, the prediction plane, the reconstruction plane or NULL; qparams rows and the inverse-scan pool uploaded once per picture).
+ * recon_offset = SVTHIP_TU_RECON_SCRATCH gives the candidate a private tile in batcher-owned scratch (tx-type search: several
+ * candidates of the same TU must not overwrite each other, and none of them is the final reconstruction). */
+typedef struct svthip_tu_batcher svthip_tu_batcher;
+#define SVTHIP_TU_RECON_SCRATCH 0xffffffffu
+
+typedef struct svthip_tu_result {
+    uint64_t distortion[2];     /* sum (coeff - dqcoeff)^2, sum coeff^2 (DIST_CALC_RESIDUAL, DIST_CALC_PREDICTION) */
+    uint64_t three_quad_energy; /* dropped 64-point quadrants (HandleTransform64x64_c) */
+    uint32_t coeff_offset;      /* of this candidate's block in the batcher's coefficient pools */
+    uint16_t eob;
+    uint8_t tx_size, tx_type;
+} svthip_tu_result;
+
+int32_t svthip_tu_batcher_create(svthip_ctx *ctx, uint32_t max_candidates, uint32_t max_coeff_samples, svthip_tu_batcher **out);
+void svthip_tu_batcher_destroy(svthip_tu_batcher *b);
+int32_t svthip_tu_batcher_begin(svthip_tu_batcher *b, const void *d_src, const void *d_pred, void *d_recon, int32_t planes_16bit,
+                                const int16_t *d_qparams, const int16_t *d_iscan);
+/* tx_size: TxSize 0..18 (TX_4X4 .. TX_64X16, Codec/EbDefinitions.h); offsets / strides in samples, as in svthip_tu_desc */
+int32_t svthip_tu_batcher_add(svthip_tu_batcher *b, uint32_t tx_size, uint32_t tx_type, uint32_t src_offset, uint32_t src_stride,
+                              uint32_t pred_offset, uint32_t pred_stride, uint32_t recon_offset, uint32_t recon_stride, uint32_t qparam_index,
+                              uint32_t iscan_offset, uint32_t *out_handle);
+/* launches everything added since _begin (or the last flush) and waits; results stay readable until the next _begin */
+int32_t svthip_tu_batcher_flush(svthip_tu_batcher *b);
+int32_t svthip_tu_batcher_result(const svthip_tu_batcher *b, uint32_t handle, svthip_tu_result *out);
+/* copies the candidate's min(W,32) x min(H,32) quantised levels / dequantised coefficients to host buffers (either may be NULL) */
+int32_t svthip_tu_batcher_read_coeffs(svthip_tu_batcher *b, uint32_t handle, int32_t *qcoeff, int32_t *dqcoeff);
+/* device addresses of the pools, for a caller that keeps the winner's levels on the device (entropy coding input) */
+int32_t svthip_tu_batcher_pools(const svthip_tu_batcher *b, const int32_t **d_qcoeff, const int32_t **d_dqcoeff, const void **d_recon_scratch);
+
+/* ---------------------------------------------------------------------------------------------
  * Reference-layout results and host-pointer forms (what a C host that owns host memory binds).
  *
  * svthip_me_cu_result_ref has the memory layout of the reference's MeCuResults_t (Codec/EbMotionEstimationLcuResults.h:56-76) as

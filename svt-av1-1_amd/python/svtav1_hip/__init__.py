@@ -122,6 +122,22 @@ def lib() -> C.CDLL:
     L.svthip_sad_loop_batch_dev.restype = C.c_int32
     L.svthip_sad_loop_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.svthip_tu_batcher_create.restype = C.c_int32
+    L.svthip_tu_batcher_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.svthip_tu_batcher_destroy.restype = None
+    L.svthip_tu_batcher_destroy.argtypes = [C.c_void_p]
+    L.svthip_tu_batcher_begin.restype = C.c_int32
+    L.svthip_tu_batcher_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.svthip_tu_batcher_add.restype = C.c_int32
+    L.svthip_tu_batcher_add.argtypes = [C.c_void_p] + [C.c_uint32] * 10 + [C.POINTER(C.c_uint32)]
+    L.svthip_tu_batcher_flush.restype = C.c_int32
+    L.svthip_tu_batcher_flush.argtypes = [C.c_void_p]
+    L.svthip_tu_batcher_result.restype = C.c_int32
+    L.svthip_tu_batcher_result.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.svthip_tu_batcher_read_coeffs.restype = C.c_int32
+    L.svthip_tu_batcher_read_coeffs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.svthip_tu_batcher_pools.restype = C.c_int32
+    L.svthip_tu_batcher_pools.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     _lib = L
     return L
 
@@ -335,6 +351,55 @@ def _pad_plane_dev(self, d_plane, stride, width, height, pad_w, pad_h, sample_by
 
 Context.pa_derive_planes_dev = _pa_derive_planes_dev
 Context.pad_plane_dev = _pad_plane_dev
+
+
+class TuResult(C.Structure):
+    _fields_ = [("distortion", C.c_uint64 * 2), ("three_quad_energy", C.c_uint64), ("coeff_offset", C.c_uint32), ("eob", C.c_uint16),
+                ("tx_size", C.c_uint8), ("tx_type", C.c_uint8)]
+
+
+TU_RECON_SCRATCH = 0xffffffff
+
+
+class TuBatcher:
+    """svthip_tu_batcher: host-side gather / scatter of (TU, tx_type) candidates for the fused T/Q chain."""
+
+    def __init__(self, ctx: "Context", max_candidates: int, max_coeff_samples: int):
+        self._h = C.c_void_p()
+        self._ctx = ctx
+        _check(lib().svthip_tu_batcher_create(ctx._h, max_candidates, max_coeff_samples, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().svthip_tu_batcher_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def begin(self, d_src, d_pred, d_recon, planes_16bit, d_qparams, d_iscan):
+        _check(lib().svthip_tu_batcher_begin(self._h, d_src, d_pred, d_recon, int(planes_16bit), d_qparams, d_iscan))
+
+    def add(self, tx_size, tx_type, src_offset, src_stride, pred_offset, pred_stride, recon_offset, recon_stride, qparam_index, iscan_offset) -> int:
+        h = C.c_uint32(0)
+        _check(lib().svthip_tu_batcher_add(self._h, tx_size, tx_type, src_offset, src_stride, pred_offset, pred_stride, recon_offset, recon_stride,
+                                           qparam_index, iscan_offset, C.byref(h)))
+        return h.value
+
+    def flush(self):
+        _check(lib().svthip_tu_batcher_flush(self._h))
+
+    def result(self, handle) -> TuResult:
+        r = TuResult()
+        _check(lib().svthip_tu_batcher_result(self._h, handle, C.byref(r)))
+        return r
+
+    def read_coeffs(self, handle, n):
+        q = np.zeros(n, np.int32); dq = np.zeros(n, np.int32)
+        _check(lib().svthip_tu_batcher_read_coeffs(self._h, handle, q.ctypes.data, dq.ctypes.data))
+        return q, dq
+
+    def pools(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().svthip_tu_batcher_pools(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
 
 def _sad_loop_batch_dev(self, d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, width, height, sw, sh, d_best_sad, d_best_xy,
