@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -55,7 +56,8 @@ void set_kernel_attrs(int device)
 {
     const void* kernels[] = {reinterpret_cast<const void*>(svthip::fullpel85_kernel),  reinterpret_cast<const void*>(svthip::fullpel209_kernel),
                              reinterpret_cast<const void*>(svthip::subpel85_kernel),   reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
-                             reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel)};
+                             reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
+                             reinterpret_cast<const void*>(svthip::subpel_planes_kernel)};
     hipError_t st = hipSuccess;
     for (const void* k : kernels) {
         hipFuncAttributes fa;
@@ -205,11 +207,21 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
         return fail(SVTHIP_ERR_BAD_PARAMETER, "search area must be 1..127%s", "");
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // default path: the half-pel planes of the whole (bounded) search region interpolated once per (SB, list) in LDS, all PUs in one launch
+    const size_t lds_planes = svthip::subpel_planes_lds_bytes(max_search_area_width, max_search_area_height);
+    if (lds_planes <= 160 * 1024 - 512 && !getenv("SVTHIP_SUBPEL_TILES")) {
+        hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(n_sb), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride, d_ref_plane,
+                           ref_stride, reinterpret_cast<const int32_t*>(d_desc), (int)(disable_8x8_refinement != 0), n_pu,
+                           d_best_sad, d_best_mv, d_pred);
+        HIP_TRY(hipGetLastError());
+        return SVTHIP_OK;
+    }
+    // search areas beyond ~120 x 120: per-PU tiles (me_subpel.hip)
     const size_t lds = svthip::subpel_lds_bytes(max_search_area_width, max_search_area_height);
     const size_t lds_nsq = svthip::subpel_nsq_lds_bytes(max_search_area_width, max_search_area_height);
     if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
                        reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv, d_pred, n_pu == 209 ? 14 : 4);
     HIP_TRY(hipGetLastError());
