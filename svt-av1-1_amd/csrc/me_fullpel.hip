@@ -32,11 +32,13 @@ namespace {
 
 __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kernel(
     const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
-    uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
+    uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, uint32_t* __restrict__ out_sad,
     uint32_t* __restrict__ out_mv)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    fullpel85_sb(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * blockIdx.x, blockIdx.x, out_sad, out_mv, smem);
+    const uint32_t sb = xcd_item(blockIdx.x, n_sb);  // raster neighbours share an XCD's L2 (me_kernels.h)
+    if (sb >= n_sb) return;
+    fullpel85_sb(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
 }
 
 }  // namespace svthip

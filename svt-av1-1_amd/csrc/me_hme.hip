@@ -24,17 +24,19 @@ namespace {
 }  // namespace
 
 __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P,
-                                                         uint32_t list_index, const svthip_sb_origin* __restrict__ sbs,
-                                                         const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
+                                                         uint32_t list_index, const svthip_sb_origin* __restrict__ sbs, uint32_t n_sb,
+                                                         uint32_t n_jobs, const uint32_t* __restrict__ l0_best_mv64, uint32_t l0_mv_stride,
                                                          svthip_fullpel_desc* __restrict__ out_desc,
                                                          int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state)
 {
     __shared__ HmeShared sh;
     __shared__ __attribute__((aligned(16))) uint8_t hme_lds[4 * kHmeLdsPerWave];
-    // blockIdx.y = job (one current/reference picture pair); all per-SB inputs and outputs of job j live at [j * n_sb + i]
-    const uint32_t sb_local = blockIdx.x;
-    const uint32_t sbi = blockIdx.y * gridDim.x + sb_local;
-    hme_center_sb(pool, jobs.cur[blockIdx.y], jobs.ref[blockIdx.y], P, list_index, sbs[sb_local].x, sbs[sb_local].y, sbi, l0_best_mv64,
+    // one block per (job, SB), job = one current / reference picture pair; all per-SB inputs and outputs of job j live at [j * n_sb + i].
+    // Blocks are mapped so that an XCD walks a contiguous range of (job, SB) pairs: raster neighbours share its L2 (me_kernels.h).
+    const uint32_t sbi = xcd_item(blockIdx.x, n_sb * n_jobs);
+    if (sbi >= n_sb * n_jobs) return;
+    const uint32_t job = sbi / n_sb, sb_local = sbi - job * n_sb;
+    hme_center_sb(pool, jobs.cur[job], jobs.ref[job], P, list_index, sbs[sb_local].x, sbs[sb_local].y, sbi, l0_best_mv64,
                   l0_mv_stride, out_desc, out_center, hme_state, sh, hme_lds);
 }
 

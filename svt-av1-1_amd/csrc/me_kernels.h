@@ -17,9 +17,20 @@
 
 namespace svthip {
 
+// XCD-aware block -> work-item map for the per-superblock kernels.  The dispatcher deals consecutive workgroups round-robin over the 8
+// XCDs (MI355X_MICROARCH.md: blocks b and b + 8 share an XCD), and every XCD has its own 4 MB L2: with item = blockIdx, raster
+// neighbours -- whose search windows overlap by half -- land on 8 different L2s and each fetches the overlap for itself.  With
+//     item = (b % 8) * ceil(n / 8) + b / 8          (grid = 8 * ceil(n / 8) blocks, items >= n exit at once)
+// an XCD works through one contiguous eighth of the superblock list, so the overlapping window rows are L2 hits.  Placement is used
+// for speed only: any block -> XCD assignment gives the same results.
+__host__ __device__ inline uint32_t xcd_grid(uint32_t n) { return 8u * ((n + 7u) >> 3); }
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t xcd_item(uint32_t b, uint32_t n) { return (b & 7u) * ((n + 7u) >> 3) + (b >> 3); }
+#endif
+
 __global__ void fullpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                  const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
-                                 const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
+                                 const int32_t* __restrict__ desc, uint32_t n_sb, uint32_t* __restrict__ out_sad,
                                  uint32_t* __restrict__ out_mv);
 
 // job table of one search-centre launch, passed by value in the kernel arguments (2.5 KB)
@@ -28,7 +39,7 @@ struct HmeJobTable {
     svthip_pa_picture ref[SVTHIP_HME_MAX_JOBS];
 };
 __global__ void hme_center_kernel(const uint8_t* __restrict__ pool, HmeJobTable jobs, svthip_me_params P, uint32_t list_index,
-                                  const svthip_sb_origin* __restrict__ sbs, const uint32_t* __restrict__ l0_best_mv64,
+                                  const svthip_sb_origin* __restrict__ sbs, uint32_t n_sb, uint32_t n_jobs, const uint32_t* __restrict__ l0_best_mv64,
                                   uint32_t l0_mv_stride, svthip_fullpel_desc* __restrict__ out_desc,
                                   int16_t* __restrict__ out_center, int16_t* __restrict__ hme_state);
 
@@ -46,8 +57,8 @@ __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t 
                                 uint32_t* __restrict__ pred_out, int pred_slots);
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
-                                     uint32_t ref_stride, const int32_t* __restrict__ desc, int disable_8x8, int n_pu, uint32_t* __restrict__ io_sad,
-                                     uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out);
+                                     uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
+                                     uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out);
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                   uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
@@ -92,7 +103,7 @@ hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int 
                             int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s);
 
 __global__ void fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
-                                  uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ out_sad,
+                                  uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, uint32_t* __restrict__ out_sad,
                                   uint32_t* __restrict__ out_mv);
 size_t fullpel209_lds_bytes(uint32_t max_sh);
 

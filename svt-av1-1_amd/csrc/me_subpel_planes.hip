@@ -332,15 +332,17 @@ __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
 // io arrays [n_sb][n_pu] in ME-buffer order, refined in place; pred_out (optional) [n_sb][slots][1024 dwords].
 __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                             const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
-                                                            const int32_t* __restrict__ desc, int disable_8x8, int n_pu, uint32_t* __restrict__ io_sad,
-                                                            uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out)
+                                                            const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
+                                                            uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
-    const int32_t* d = desc + 6 * blockIdx.x;
+    const uint32_t sb = xcd_item(blockIdx.x, n_sb);  // raster neighbours share an XCD's L2 (me_kernels.h)
+    if (sb >= n_sb) return;
+    const int32_t* d = desc + 6 * sb;
     const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
-    uint32_t* sad_io = io_sad + (size_t)n_pu * blockIdx.x;
-    uint32_t* mv_io = io_mv + (size_t)n_pu * blockIdx.x;
+    uint32_t* sad_io = io_sad + (size_t)n_pu * sb;
+    uint32_t* mv_io = io_mv + (size_t)n_pu * sb;
 
     // LDS: [bbox 4 ints + shake 25 words -> 128 B][A][b][h][j]
     lds_u32* ctl = (lds_u32*)smem;
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.yo = yo;
     c.sad_io = sad_io;
     c.mv_io = mv_io;
-    c.pred = pred_out ? pred_out + (size_t)blockIdx.x * (n_pu == 209 ? 14 : 4) * 1024 : nullptr;
+    c.pred = pred_out ? pred_out + (size_t)sb * (n_pu == 209 ? 14 : 4) * 1024 : nullptr;
     c.shake = ctl + 4;
     c.lane = lane;
     const int n_tasks = n_pu == 209 ? 28 : 8;

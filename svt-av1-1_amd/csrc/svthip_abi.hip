@@ -120,8 +120,8 @@ int32_t launch_fullpel(svthip_ctx* ctx, const uint8_t* d_src, uint32_t src_strid
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     const size_t lds = svthip::fullpel_lds_bytes(max_sh);
-    hipLaunchKernelGGL(svthip::fullpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src, src_stride, d_ref, ref_stride,
-                       reinterpret_cast<const int32_t*>(d_desc), d_sad, d_mv);
+    hipLaunchKernelGGL(svthip::fullpel85_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(256), lds, s, d_src, src_stride, d_ref, ref_stride,
+                       reinterpret_cast<const int32_t*>(d_desc), n_sb, d_sad, d_mv);
     HIP_TRY(hipGetLastError());
     return SVTHIP_OK;
 }
@@ -211,8 +211,8 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
     // default path: the half-pel planes of the whole (bounded) search region interpolated once per (SB, list) in LDS, all PUs in one launch
     const size_t lds_planes = svthip::subpel_planes_lds_bytes(max_search_area_width, max_search_area_height);
     if (lds_planes <= 160 * 1024 - 512 && !getenv("SVTHIP_SUBPEL_TILES")) {
-        hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(n_sb), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride, d_ref_plane,
-                           ref_stride, reinterpret_cast<const int32_t*>(d_desc), (int)(disable_8x8_refinement != 0), n_pu,
+        hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
+                           d_ref_plane, ref_stride, reinterpret_cast<const int32_t*>(d_desc), n_sb, (int)(disable_8x8_refinement != 0), n_pu,
                            d_best_sad, d_best_mv, d_pred);
         HIP_TRY(hipGetLastError());
         return SVTHIP_OK;
@@ -361,8 +361,8 @@ int32_t svthip_me_fullpel_search209_dev(svthip_ctx* ctx, const uint8_t* d_src_pl
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     const size_t lds = svthip::fullpel209_lds_bytes(max_search_area_height);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(svthip::fullpel209_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                       reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv);
+    hipLaunchKernelGGL(svthip::fullpel209_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
+                       reinterpret_cast<const int32_t*>(d_desc), n_sb, d_best_sad, d_best_mv);
     HIP_TRY(hipGetLastError());
     return SVTHIP_OK;
 }
@@ -487,8 +487,8 @@ int32_t svthip_me_hme_search_center_batch_dev(svthip_ctx* ctx, const uint8_t* d_
         const uint32_t* mv64 = d_l0_best_mv64 ? d_l0_best_mv64 + base * mvs : nullptr;
         int16_t* cen = d_center ? d_center + 2 * base : nullptr;
         int16_t* st = d_hme_state ? d_hme_state + SVTHIP_HME_STATE_INT16 * base : nullptr;
-        hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(n_sb, nj), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb, mv64, mvs,
-                           d_desc + base, cen, st);
+        hipLaunchKernelGGL(svthip::hme_center_kernel, dim3(svthip::xcd_grid(n_sb * nj)), dim3(256), 0, s, d_pool, jt, P, list_index, d_sb, n_sb, nj, mv64,
+                           mvs, d_desc + base, cen, st);
         HIP_TRY(hipGetLastError());
     }
     return SVTHIP_OK;
