@@ -198,6 +198,41 @@ class Oracle:
         f(full.ctypes.data, fs, w, h, quarter.ctypes.data, qs, sixteenth.ctypes.data, ss)
         return full, quarter, sixteenth
 
+    # ---- open-loop intra search (oracle/svt_ois_oracle.c) ----
+    def ois_neighbours(self, plane, origin, width, height, cu_x, cu_y, size):
+        refs = np.zeros(4 * size + 1, np.uint8)
+        self.lib.orc_ois_neighbours.restype = None
+        self.lib.orc_ois_neighbours(C.c_void_p(plane.ctypes.data), plane.shape[1], origin, width, height, cu_x, cu_y, size,
+                                    C.c_void_p(refs.ctypes.data))
+        return refs
+
+    def ois_predict(self, refs, size, mode):
+        pred = np.zeros((size, size), np.uint8)
+        self.lib.orc_ois_predict.restype = None
+        self.lib.orc_ois_predict(C.c_void_p(refs.ctypes.data), size, mode, C.c_void_p(pred.ctypes.data))
+        return pred
+
+    def ois_sad_table(self, plane, origin, width, height):
+        n_sb = ((width + 63) // 64) * ((height + 63) // 64)
+        out = np.zeros((n_sb, 85, 35), np.uint32)
+        self.lib.orc_ois_sad_table(C.c_void_p(plane.ctypes.data), plane.shape[1], origin, width, height,
+                                   C.c_void_p(out.ctypes.data))
+        return out
+
+    def ois_search_picture(self, plane, origin, width, height, op, me_dist=None):
+        """op = OIS_PARAMS-ordered int32[7]; returns (cand [n_sb][85][18] u32, total [n_sb][85] u8)."""
+        n_sb = ((width + 63) // 64) * ((height + 63) // 64)
+        cand = np.zeros((n_sb, 85, 18), np.uint32)
+        total = np.zeros((n_sb, 85), np.uint8)
+        op = np.ascontiguousarray(op, np.int32)
+        md = None if me_dist is None else np.ascontiguousarray(me_dist, np.uint32)
+        self.lib.orc_ois_search_picture.restype = C.c_int
+        rc = self.lib.orc_ois_search_picture(C.c_void_p(plane.ctypes.data), plane.shape[1], origin, width, height,
+                                             C.c_void_p(op.ctypes.data), C.c_void_p(None if md is None else md.ctypes.data),
+                                             C.c_void_p(cand.ctypes.data), C.c_void_p(total.ctypes.data))
+        assert rc == 0
+        return cand, total
+
     def sad_loop(self, src, src_off, src_stride, ref, ref_off, ref_stride, height, width, ref_stride_raw, sw, sh):
         best = C.c_uint64(0)
         x = C.c_int16(-12345)
@@ -265,6 +300,28 @@ class ReferenceME:
         self.lib.ref_me_lcu_run.restype = C.c_int
         self.lib.ref_me_lcu_run.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+
+    def ois_predict(self, plane, origin, width, height, cu_x, cu_y, size, mode):
+        pred = np.zeros((size, size), np.uint8)
+        refs = np.zeros(4 * size + 1, np.uint8)
+        self.lib.ref_ois_predict.restype = C.c_int
+        rc = self.lib.ref_ois_predict(C.c_void_p(plane.ctypes.data), plane.shape[1], origin, width, height, cu_x, cu_y, size,
+                                      mode, C.c_void_p(pred.ctypes.data), C.c_void_p(refs.ctypes.data))
+        assert rc == 0
+        return pred, refs
+
+    def ois_search_picture(self, plane, origin, width, height, op, me_dist=None):
+        n_sb = ((width + 63) // 64) * ((height + 63) // 64)
+        cand = np.zeros((n_sb, 85, 18), np.uint32)
+        total = np.zeros((n_sb, 85), np.uint8)
+        op = np.ascontiguousarray(op, np.int32)
+        md = None if me_dist is None else np.ascontiguousarray(me_dist, np.uint32)
+        self.lib.ref_ois_search_picture.restype = C.c_int
+        rc = self.lib.ref_ois_search_picture(C.c_void_p(plane.ctypes.data), plane.shape[1], origin, width, height,
+                                             C.c_void_p(op.ctypes.data), C.c_void_p(None if md is None else md.ctypes.data),
+                                             C.c_void_p(cand.ctypes.data), C.c_void_p(total.ctypes.data))
+        assert rc == 0
+        return cand, total
 
     def fullpel_search209_batch(self, src_plane, ref_plane, desc):
         """The reference's ExtSadCalculation* functions driven like open_loop_me_fullpel_search_sblock
