@@ -255,6 +255,32 @@ def leg_me_chain(ctx, torch, svtav1_hip, timer, pool, descs, params_b, d_sb, n_s
     return out
 
 
+def leg_ois(ctx, torch, svtav1_hip, timer, pool, descs, params_b, d_sb, n_sb, dev):
+    """OpenLoopIntraSearchLcu of 12 x 1080p pictures per call, after the ME of the same pictures (its distortions feed
+    the general branch).  Algorithmic pixel work per SB and mode: 3 CU levels x 4096 predicted pixels + SAD."""
+    n_jobs = PICTURES_PER_STEP
+    curs = [descs[i + 1] for i in range(n_jobs)]
+    r0 = [descs[i] for i in range(n_jobs)]
+    r1 = [descs[(i + 2) % len(descs)] for i in range(n_jobs)]
+    d_me = torch.zeros((n_jobs * n_sb, 85, 24), dtype=torch.uint8, device=dev)
+    ctx.motion_estimate_batch_dev(pool.data_ptr(), curs, r0, r1, params_b, d_sb.data_ptr(), n_sb, d_me.data_ptr(), True, 0, None, None, timer.stream)
+    d_cand = torch.zeros((n_jobs * n_sb, 85, 18), dtype=torch.int32, device=dev)
+    d_total = torch.zeros((n_jobs * n_sb, 85), dtype=torch.uint8, device=dev)
+    out = {}
+    for name, modes, kw in (("intra_picture", 7, dict(slice_is_intra=1)), ("base_layer_35_modes", 35, dict(temporal_layer_index=0)),
+                            ("general_branch", 10, dict(temporal_layer_index=2, is_used_as_reference_flag=1)),
+                            ("dc_only", 1, dict(temporal_layer_index=3, limit_ois_to_dc_mode_flag=1))):
+        prm = svtav1_hip.OisParams()
+        for k, v in kw.items():
+            setattr(prm, k, v)
+        ms = timer.ms(lambda: ctx.open_loop_intra_search_batch_dev(pool.data_ptr(), curs, prm, d_sb.data_ptr(), n_sb, d_me.data_ptr(), 85,
+                                                                   d_cand.data_ptr(), d_total.data_ptr(), timer.stream), 5)
+        out[name] = {"ms_per_picture": round(ms / n_jobs, 4), "modes_evaluated": modes,
+                     "gpix_predicted_per_s": round(n_jobs * n_sb * 3 * 4096 * modes / ms * 1e-6, 1)}
+    out["workload"] = "12 x 1080p pictures per call; 84 CUs (4 + 16 + 64) per SB; every mode of the branch's list for every CU, then the per-CU decision"
+    return out
+
+
 def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
     """configs[3]: fused encode chain (residual -> fwd txfm -> quant -> dequant -> inv txfm -> recon) per square size, (a) on one
     1080p luma frame of TUs (SURVEY 8d config 4 shapes) and (b) on a 64 M-pixel plane for the roofline fraction (working set beyond
@@ -603,6 +629,7 @@ def main():
             d_sb_all = torch.from_numpy(sb_all.view(np.int16).copy()).to(dev)
             params_b = svtav1_hip.default_me_params(W, H, 3, 1)
             legs["me_chain_subpel"] = leg_me_chain(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
+            legs["open_loop_intra_search"] = leg_ois(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
             legs["sad_loop_480p"] = leg_sad_loop(ctx, torch, svtav1_hip, timer, dev)
             legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
             legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)

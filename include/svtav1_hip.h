@@ -562,6 +562,46 @@ int32_t svthip_encode_tu_batch(svthip_ctx *ctx, const void *src, const void *pre
                                uint32_t n_qparam_rows, const int16_t *iscan, uint32_t n_iscan, size_t coeff_samples, int32_t *coeff,
                                int32_t *qcoeff, int32_t *dqcoeff, uint16_t *eob, uint64_t *three_quad_energy, uint64_t *distortion);
 
+/* ---------------------------------------------------------------------------------------------
+ * Open-loop intra search: OpenLoopIntraSearchLcu (Codec/EbMotionEstimation.c:8047-8355), which the ME process
+ * runs for every SB right after MotionEstimateLcu (Codec/EbMotionEstimationProcess.c:558-579), for n_jobs pictures of equal
+ * geometry in one launch: neighbour samples from the SOURCE picture (UpdateNeighborSamplesArrayOpenLoop,
+ * Codec/EbIntraPrediction.c:5233), the 35 HEVC-style luma predictors (IntraPredictionOpenLoop, :5353), plain SAD, and the
+ * candidate selection of the picture's branch:
+ *   slice_is_intra                                    : 7 modes, best-mode based list (:8076-8153)
+ *   temporal_layer_index == 0 && !input_resolution_4k : all 35 modes, best 18 sorted by SAD (:8219-8270)
+ *   limit_ois_to_dc_mode_flag                         : DC only (OpenLoopIntraDC, :7951)
+ *   otherwise                                         : DC SAD vs the CU's ME distortion -> OIS point -> 1..9 stage-1 modes ->
+ *                                                       injected list (GetInterIntraSadDistance / GetOisPoint /
+ *                                                       InjectIntraCandidatesBasedOnBestMode, :7525-7852); needs d_me
+ * cur: HOST array of n_jobs picture descriptors (only the full-resolution plane is read; origin (68,68)).
+ * d_me: the ME results of the same (job, SB) items, [n_jobs * n_sb][me_pu_stride] (85 or 209) in raster PU order, of which
+ *       entry [cu].distortion[0] is read for cu = 1..84 (me_results[sb][rasterScanCuIndex].distortionDirection[0], :8291).
+ * Outputs, per (job, SB) item and raster CU index 0..84 (RASTER_SCAN_CU_INDEX, 0 = the unused 64x64 slot):
+ *   d_cand  [n_jobs * n_sb][85][18] : OisCandidate_t words (distortion : 20, valid_distortion : 1, - : 3, intra_mode : 8;
+ *                                     Codec/EbCodingUnit.h:303-313), i.e. sorted_ois_candidate[cu][0..17]
+ *   d_total [n_jobs * n_sb][85]     : total_intra_luma_mode[cu]
+ * Every word is written; fields the reference leaves untouched (it keeps what an earlier picture stored there: e.g.
+ * distortion of candidates 1..8 on the general branch, total_intra_luma_mode of 32x32 CUs of I pictures, everything of CUs
+ * that are not wholly inside the picture) are written as 0, so a host copy-out should copy only what the branch defines
+ * (INTEGRATION.md 1.8).  ASM_NON_AVX2 semantics (the AVX2 DC-only shortcut UpdateNeighborDcIntraPred_AVX2_INTRIN is not
+ * reproduced). */
+typedef struct svthip_ois_params {
+    uint8_t slice_is_intra;             /* slice_type == I_SLICE */
+    uint8_t temporal_layer_index;       /* 0..5 */
+    uint8_t is_used_as_reference_flag;
+    uint8_t input_resolution_4k;        /* sequence input_resolution == INPUT_SIZE_4K_RANGE */
+    uint8_t limit_ois_to_dc_mode_flag;
+    uint8_t cu8x8_mode;                 /* 1 = CU_8x8_MODE_1: 8x8 CUs are skipped on non-intra pictures (:8203) */
+    uint8_t enc_mode;                   /* only read for the vertical winner's valid flag (:7609) */
+    uint8_t reserved;
+} svthip_ois_params;
+
+int32_t svthip_open_loop_intra_search_batch_dev(svthip_ctx *ctx, const uint8_t *d_pool, const svthip_pa_picture *cur,
+                                                uint32_t n_jobs, const svthip_ois_params *params,
+                                                const svthip_sb_origin *d_sb, uint32_t n_sb, const svthip_me_cu_result *d_me,
+                                                uint32_t me_pu_stride, uint32_t *d_cand, uint8_t *d_total, void *stream);
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

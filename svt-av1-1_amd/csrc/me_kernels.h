@@ -49,6 +49,9 @@ struct PaJobTable {
 };
 __global__ void pa_derive_planes_kernel(uint8_t* __restrict__ pool, PaJobTable jobs, int do_quarter, int do_sixteenth);
 __global__ void me_results_ref_layout_kernel(const svthip_me_cu_result* __restrict__ in, uint32_t n, svthip_me_cu_result_ref* __restrict__ out);
+__global__ void ois_kernel(const uint8_t* __restrict__ pool, PaJobTable jobs, svthip_ois_params P, const svthip_sb_origin* __restrict__ sbs,
+                           uint32_t n_sb, uint32_t n_jobs, const svthip_me_cu_result* __restrict__ me, uint32_t me_stride,
+                           uint32_t* __restrict__ out_cand, uint8_t* __restrict__ out_total);
 hipError_t launch_pad_plane(void* plane, uint32_t stride, int width, int height, int pad_w, int pad_h, int sample_bytes, hipStream_t s);
 
 __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,

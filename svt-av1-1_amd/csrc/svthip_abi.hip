@@ -743,6 +743,40 @@ int32_t svthip_me_results_to_ref_layout_dev(svthip_ctx* ctx, const svthip_me_cu_
     return SVTHIP_OK;
 }
 
+int32_t svthip_open_loop_intra_search_batch_dev(svthip_ctx* ctx, const uint8_t* d_pool, const svthip_pa_picture* cur, uint32_t n_jobs,
+                                                const svthip_ois_params* params, const svthip_sb_origin* d_sb, uint32_t n_sb,
+                                                const svthip_me_cu_result* d_me, uint32_t me_pu_stride, uint32_t* d_cand, uint8_t* d_total,
+                                                void* stream)
+{
+    ENTER(ctx);
+    if (n_jobs == 0 || n_sb == 0) return SVTHIP_OK;
+    if (!d_pool || !cur || !params || !d_sb || !d_cand || !d_total) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (params->temporal_layer_index > 5) return fail(SVTHIP_ERR_BAD_PARAMETER, "temporal_layer_index must be 0..5%s (got %d)", "", (int)params->temporal_layer_index);
+    const bool general = !params->slice_is_intra && !(params->temporal_layer_index == 0 && !params->input_resolution_4k) &&
+                         !params->limit_ois_to_dc_mode_flag;
+    if (general && (!d_me || (me_pu_stride != 85 && me_pu_stride != 209)))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "this picture's branch reads the ME distortions: d_me with me_pu_stride 85 or 209 is required%s (stride %d)", "", (int)me_pu_stride);
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const svthip_pa_picture& p = cur[j];
+        if ((p.width & 7) || (p.height & 7) || p.width == 0 || p.height == 0 || p.width != cur[0].width || p.height != cur[0].height)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be equal non-zero multiples of 8%s (picture %d)", "", (int)j);
+        if (p.full_stride < (uint32_t)p.width + 136u || (p.full_stride & 3u) || (p.full_offset & 3) || p.full_offset < 0)
+            return fail(SVTHIP_ERR_BAD_PARAMETER, "full-resolution stride must be a multiple of 4 and >= width + 136, offset a multiple of 4%s (picture %d)", "", (int)j);
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    for (uint32_t j0 = 0; j0 < n_jobs; j0 += SVTHIP_HME_MAX_JOBS) {
+        const uint32_t nj = (n_jobs - j0 < SVTHIP_HME_MAX_JOBS) ? n_jobs - j0 : SVTHIP_HME_MAX_JOBS;
+        svthip::PaJobTable jt;
+        memset(&jt, 0, sizeof(jt));
+        for (uint32_t j = 0; j < nj; j++) jt.pic[j] = cur[j0 + j];
+        const size_t first = (size_t)j0 * n_sb;
+        hipLaunchKernelGGL(svthip::ois_kernel, dim3(svthip::xcd_grid(n_sb * nj)), dim3(256), 0, s, d_pool, jt, *params, d_sb, n_sb, nj,
+                           d_me ? d_me + first * me_pu_stride : nullptr, me_pu_stride, d_cand + first * 85 * 18, d_total + first * 85);
+        HIP_TRY(hipGetLastError());
+    }
+    return SVTHIP_OK;
+}
+
 int32_t svthip_motion_estimate_picture(svthip_ctx* ctx, const svthip_host_picture* cur, const svthip_host_picture* ref0,
                                        const svthip_host_picture* ref1, const svthip_me_params* params, int32_t use_subpel_flag,
                                        int32_t cu8x8_mode, uint32_t n_pu, void* const* me_results)

@@ -114,6 +114,9 @@ def lib() -> C.CDLL:
                                              C.c_uint32] + [C.c_void_p] * 9
     L.svthip_pa_derive_planes_dev.restype = C.c_int32
     L.svthip_pa_derive_planes_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p]
+    L.svthip_open_loop_intra_search_batch_dev.restype = C.c_int32
+    L.svthip_open_loop_intra_search_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                          C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.svthip_pad_plane_dev.restype = C.c_int32
     L.svthip_pad_plane_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.svthip_av1_convolve_sr_batch_dev.restype = C.c_int32
@@ -349,6 +352,23 @@ def _pad_plane_dev(self, d_plane, stride, width, height, pad_w, pad_h, sample_by
     _check(lib().svthip_pad_plane_dev(self._h, d_plane, stride, width, height, pad_w, pad_h, sample_bytes, stream))
 
 
+HME_MAX_JOBS = 32  # SVTHIP_HME_MAX_JOBS: pictures per kernel launch of the batch entries
+
+
+class OisParams(C.Structure):
+    _fields_ = [("slice_is_intra", C.c_uint8), ("temporal_layer_index", C.c_uint8), ("is_used_as_reference_flag", C.c_uint8),
+                ("input_resolution_4k", C.c_uint8), ("limit_ois_to_dc_mode_flag", C.c_uint8), ("cu8x8_mode", C.c_uint8),
+                ("enc_mode", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+def _open_loop_intra_search_batch_dev(self, d_pool, curs, params, d_sb, n_sb, d_me, me_pu_stride, d_cand, d_total, stream=None):
+    """OpenLoopIntraSearchLcu over len(curs) pictures: d_cand [n][n_sb][85][18] u32 OisCandidate_t words, d_total [n][n_sb][85] u8."""
+    n = len(curs)
+    _check(lib().svthip_open_loop_intra_search_batch_dev(self._h, d_pool, (PaPictureDesc * n)(*curs), n, C.byref(params), d_sb, n_sb,
+                                                         d_me, me_pu_stride, d_cand, d_total, stream))
+
+
+Context.open_loop_intra_search_batch_dev = _open_loop_intra_search_batch_dev
 Context.pa_derive_planes_dev = _pa_derive_planes_dev
 Context.pad_plane_dev = _pad_plane_dev
 
