@@ -176,6 +176,16 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 
         const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
 
+        // software-pipelined row steps, as in me_fullpel_impl.h: the window row and source row of step n + 1 are requested before the
+        // 16 v_qsad of step n
+        uint4 An, Bn;
+        uint32_t Sn[4];
+        {
+            An = *reinterpret_cast<const uint4*>(wbase);
+            Bn = *reinterpret_cast<const uint4*>(wbase + 16);
+#pragma unroll
+            for (int h = 0; h < 4; h++) Sn[h] = src4[h];
+        }
 #pragma unroll
         for (int zz = 0; zz < 4; zz++) {
             const int C = zz & 1, R = zz >> 1;
@@ -183,9 +193,23 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 
 #pragma unroll
             for (int r8 = 0; r8 < 8; r8++) {
-                const uint8_t* p = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
-                const uint4 A = *reinterpret_cast<const uint4*>(p);
-                const uint4 B = *reinterpret_cast<const uint4*>(p + 16);
+                const uint4 A = An, B = Bn;
+                const uint32_t S[4] = {Sn[0], Sn[1], Sn[2], Sn[3]};
+                asm volatile("" ::"v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), "s"(S[0]), "s"(S[1]), "s"(S[2]), "s"(S[3]));
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int nstep = zz * 8 + r8 + 1;
+                    if (nstep < 32) {
+                        const int nzz = nstep >> 3, nr8 = nstep & 7, nC = nzz & 1, nR = nzz >> 1;
+                        const uint8_t* p = wbase + (16 * nR + 2 * nr8) * kPitch + 16 * nC;
+                        An = *reinterpret_cast<const uint4*>(p);
+                        Bn = *reinterpret_cast<const uint4*>(p + 16);
+                        const uint32_t* nsrow = src4 + (16 * nR + 2 * nr8) * sstride4 + 4 * nC;
+#pragma unroll
+                        for (int h = 0; h < 4; h++) Sn[h] = nsrow[h];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // window dword pairs (W[k], W[k+1]), k = 0..6: the even ones are the loaded register pairs, the odd ones are formed
                 // with one v_pk_mov_b32 each (hi of one pair, lo of the next).  Left to the compiler they cost two v_mov each
                 // and, under register pressure (209-PU kernel), a round trip through scratch memory.
@@ -195,10 +219,6 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O1) : "v"(E1), "v"(E2));
                 asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O2) : "v"(E2), "v"(E3));
                 const uint64_t PR[7] = {E0, O0, E1, O1, E2, O2, E3};
-                const uint32_t* srow = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
-                uint32_t S[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) S[h] = srow[h];  // uniform address, read-only -> s_load_dwordx4
                 const int krow = (r8 >> 2) * 2;
 #pragma unroll
                 for (int q = 0; q < 4; q++)

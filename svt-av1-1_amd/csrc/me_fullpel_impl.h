@@ -139,21 +139,43 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
 
         const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
 
+        // The 32 (16x16 sub-block, row) steps are software-pipelined: the window row (two ds_read_b128) and the source row (one
+        // s_load_dwordx4) of step n + 1 are issued before the 16 v_qsad of step n, so their latency hides behind ~260 issue cycles
+        // instead of being waited for at the top of every row (12 more live VGPRs; the kernel stays at three workgroups per CU).
+        uint4 An, Bn;
+        uint32_t Sn[4];
+        {
+            An = *reinterpret_cast<const uint4*>(wbase);
+            Bn = *reinterpret_cast<const uint4*>(wbase + 16);
+#pragma unroll
+            for (int h = 0; h < 4; h++) Sn[h] = src4[h];  // uniform address, read-only -> s_load_dwordx4
+        }
 #pragma unroll
         for (int zz = 0; zz < 4; zz++) {
-            const int C = zz & 1, R = zz >> 1;
             uint64_t acc[4][4];
 
 #pragma unroll
             for (int r8 = 0; r8 < 8; r8++) {
-                const uint8_t* p = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
-                const uint4 A = *reinterpret_cast<const uint4*>(p);
-                const uint4 B = *reinterpret_cast<const uint4*>(p + 16);
+                const uint4 A = An, B = Bn;
                 const uint32_t W[8] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w};
-                const uint32_t* srow = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
-                uint32_t S[4];
+                const uint32_t S[4] = {Sn[0], Sn[1], Sn[2], Sn[3]};
+                // this step's operands were requested one step ago: make the s_waitcnt for them land HERE, before the next requests go
+                // out (scalar loads return out of order, so any later wait would be lgkmcnt(0) and cover the fresh requests too)
+                asm volatile("" ::"v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), "s"(S[0]), "s"(S[1]), "s"(S[2]), "s"(S[3]));
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const int nstep = zz * 8 + r8 + 1;
+                    if (nstep < 32) {
+                        const int nzz = nstep >> 3, nr8 = nstep & 7, nC = nzz & 1, nR = nzz >> 1;
+                        const uint8_t* p = wbase + (16 * nR + 2 * nr8) * kPitch + 16 * nC;
+                        An = *reinterpret_cast<const uint4*>(p);
+                        Bn = *reinterpret_cast<const uint4*>(p + 16);
+                        const uint32_t* srow = src4 + (16 * nR + 2 * nr8) * sstride4 + 4 * nC;
 #pragma unroll
-                for (int h = 0; h < 4; h++) S[h] = srow[h];  // uniform address, read-only -> s_load_dwordx4
+                        for (int h = 0; h < 4; h++) Sn[h] = srow[h];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the loads above this step's arithmetic (the scheduler sinks them to their use)
+                }
                 const int krow = (r8 >> 2) * 2;
 #pragma unroll
                 for (int q = 0; q < 4; q++)

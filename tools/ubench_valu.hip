@@ -153,6 +153,30 @@ int main()
         {"v_qsad sgpr src1", bench<33>},
     };
     const int ninstr = ITER * 32;
+    if (getenv("UB_BLOCKS")) {
+        // occupancy built from k independent 256-thread workgroups per CU (the ME kernels' shape) instead of one large workgroup
+        printf("%-22s   per-wave cycles per instruction (median) at k = 1..6 workgroups of 256 threads per CU; (SIMD rate = value / k)\n", "instr");
+        for (auto& e : tab) {
+            if (!(strstr(e.name, "sad") || strstr(e.name, "mix") || strstr(e.name, "v_add_u32") || strstr(e.name, "v_min3"))) continue;
+            printf("%-22s", e.name);
+            for (int k = 1; k <= 6; k++) {
+                const int blocks = nblk * k;
+                for (int rep = 0; rep < 2; rep++) {
+                    hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, cyc, 12345u + rep);
+                    HIPCHECK(hipDeviceSynchronize());
+                }
+                std::vector<uint64_t> h((size_t)blocks * 4);
+                HIPCHECK(hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost));
+                std::sort(h.begin(), h.end());
+                int extra = (strcmp(e.name, "v_cmp+v_cndmask") == 0) ? 2 : (strstr(e.name, "(x5)") ? 5 : 1);
+                const double med = (double)h[h.size() / 2] / (ninstr * extra), lo = (double)h[h.size() / 10] / (ninstr * extra),
+                             hi = (double)h[h.size() * 9 / 10] / (ninstr * extra);
+                printf("  k%d %6.2f [%5.2f %5.2f] (%5.2f)", k, med, lo, hi, med / k);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
     printf("%-22s %10s %10s %10s   (SIMD cycles per wave-instruction at 1/2/4 waves per SIMD)\n", "instr", "1w", "2w", "4w");
     for (auto& e : tab) {
         double res[6];
