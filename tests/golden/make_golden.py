@@ -154,7 +154,113 @@ def quant_tables_fixture():
     np.savez_compressed(os.path.join(HERE, "quant_tables.npz"), **out)
 
 
+OIS_CASES = [dict(slice_i=1), dict(temporal_layer=0), dict(temporal_layer=0, res_4k=1, is_ref=1), dict(temporal_layer=1, is_ref=1),
+             dict(temporal_layer=3), dict(temporal_layer=3, res_4k=1), dict(temporal_layer=3, limit_dc=1), dict(temporal_layer=2, cu8x8_mode=1),
+             dict(temporal_layer=2, enc_mode=3, res_4k=1)]
+OIS_OP = dict(slice_i=0, temporal_layer=1, is_ref=2, res_4k=3, limit_dc=4, cu8x8_mode=5, enc_mode=6)
+
+
+def ois_fixture():
+    """OpenLoopIntraSearchLcu (oracle/ref_ois_driver.c) on a 200x136 picture (partial SBs right and below) through every branch, with
+    synthetic ME distortions spread around the DC SADs; plus all 35 predictors of a few CUs."""
+    from oracle.binding import Oracle
+    refme, orc = ReferenceME(), Oracle()
+    w, h = 200, 136
+    luma = synth.synth_luma(w, h, 4)
+    plane = np.ascontiguousarray(np.pad(luma, 68, mode="edge"))
+    tab = orc.ois_sad_table(plane, 68, w, h)
+    rng = np.random.default_rng(20261004)
+    out = {"luma": luma}
+    ops, mes, cands, totals = [], [], [], []
+    for i, c in enumerate(OIS_CASES):
+        op = np.zeros(7, np.int32)
+        for k, v in c.items():
+            op[OIS_OP[k]] = v
+        scale = rng.choice([0.0, 0.1, 0.5, 0.9, 1.0, 1.5, 2.2, 3.5, 6.0], size=tab.shape[:2])
+        me = (tab[:, :, 1].astype(np.float64) * scale).astype(np.uint32)
+        cand, total = refme.ois_search_picture(plane, 68, w, h, op, me)
+        ops.append(op); mes.append(me); cands.append(cand); totals.append(total)
+    out.update(op=np.stack(ops), me=np.stack(mes), cand=np.stack(cands), total=np.stack(totals))
+    preds = []
+    for (cx, cy, s) in ((0, 0, 8), (64, 32, 32), (184, 120, 16), (192, 8, 8), (16, 128, 8)):
+        for mode in range(35):
+            pr, _ = refme.ois_predict(plane, 68, w, h, cx, cy, s, mode)
+            preds.append(np.pad(pr, ((0, 32 - s), (0, 32 - s))))
+    out["pred_cus"] = np.array([(0, 0, 8), (64, 32, 32), (184, 120, 16), (192, 8, 8), (16, 128, 8)], np.int32)
+    out["pred"] = np.stack(preds).reshape(5, 35, 32, 32)
+    np.savez_compressed(os.path.join(HERE, "ois.npz"), **out)
+
+
+def convolve_fixture():
+    """av1_convolve_{2d,x,y,2d_copy}_sr_c driven like av1_inter_prediction (oracle/ref_convolve_driver.c): four block sizes, 60 (14 for the large ones) blocks
+    each with random phases / filters (copy, x-only, y-only and 2-D all present), one source picture with both clips."""
+    import ctypes as C
+    me = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), mode=os.RTLD_LAZY)
+    me.ref_av1_convolve_sr.restype = None
+    me.ref_av1_convolve_sr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(77)
+    S, R = 256, 192
+    src = rng.integers(0, 256, (R, S), dtype=np.uint8)
+    src[:24] = (((np.arange(S)[None, :] // 2 + np.arange(24)[:, None] // 3) & 1) * 255).astype(np.uint8)
+    out = {"src": src}
+    for (w, h) in ((4, 4), (8, 16), (32, 8), (64, 64)):
+        n = 60 if w * h <= 256 else 14
+        d = np.zeros((n, 6), np.int32)   # sx, sy (top-left source sample), subpel_x, subpel_y, filter_x, filter_y
+        res = np.zeros((n, h, w), np.uint8)
+        for i in range(n):
+            d[i] = (rng.integers(8, S - w - 8), rng.integers(8, R - h - 8), rng.integers(0, 16), rng.integers(0, 16), rng.integers(0, 4), rng.integers(0, 4))
+        d[:4, 2] = [0, 0, 5, 15]; d[:4, 3] = [0, 7, 0, 15]
+        for i in range(n):
+            me.ref_av1_convolve_sr(src.ctypes.data + int(d[i, 1]) * S + int(d[i, 0]), S, res[i].ctypes.data, w, w, h, int(d[i, 4]), int(d[i, 5]),
+                                   int(d[i, 2]), int(d[i, 3]))
+        out[f"desc_{w}x{h}"] = d
+        out[f"out_{w}x{h}"] = res
+    np.savez_compressed(os.path.join(HERE, "convolve.npz"), **out)
+
+
+def pa_sadloop_fixture():
+    """Picture-analysis planes (the reference's generate_padding + Decimation2D sequence of DecimateInputPicture) of a 72x40 picture, and
+    SadLoopKernel (reference C) results for 16x16 +-16 and a row-skipping HME-style shape."""
+    import ctypes as C
+    me = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), mode=os.RTLD_LAZY)
+    for f in (me.generate_padding, me.Decimation2D):
+        f.restype = None
+    w, h = 72, 40
+    luma = synth.synth_luma(w, h, 9)
+    full = np.zeros((h + 136, w + 136), np.uint8); full[68:68 + h, 68:68 + w] = luma
+    me.generate_padding(C.c_void_p(full.ctypes.data), C.c_uint32(w + 136), C.c_uint32(w), C.c_uint32(h), C.c_uint32(68), C.c_uint32(68))
+    planes = {}
+    for name, step, pad in (("quarter", 2, 32), ("sixteenth", 4, 16)):
+        pw, ph = w // step, h // step
+        pl = np.zeros((ph + 2 * pad, pw + 2 * pad), np.uint8)
+        me.Decimation2D(C.c_void_p(full.ctypes.data + 68 * (w + 136) + 68), C.c_uint32(w + 136), C.c_uint32(w), C.c_uint32(h),
+                        C.c_void_p(pl.ctypes.data + pad * (pw + 2 * pad) + pad), C.c_uint32(pw + 2 * pad), C.c_uint32(step))
+        me.generate_padding(C.c_void_p(pl.ctypes.data), C.c_uint32(pw + 2 * pad), C.c_uint32(pw), C.c_uint32(ph), C.c_uint32(pad), C.c_uint32(pad))
+        planes[name] = pl
+    ref = Reference()
+    cur = synth.PaPicture(synth.synth_luma(192, 136, 1)).full
+    rf = synth.PaPicture(synth.synth_luma(192, 136, 0)).full
+    S = cur.shape[1]
+    rng = np.random.default_rng(3)
+    out = dict(luma=luma, full=full, quarter=planes["quarter"], sixteenth=planes["sixteenth"], sl_cur=cur[68:-68, 68:-68].copy(), sl_ref=rf[68:-68, 68:-68].copy())
+    for name, (bw, bh, sw, sh, k) in (("a", (16, 16, 33, 33, 1)), ("b", (32, 16, 16, 16, 2)), ("c", (24, 13, 19, 11, 1))):
+        n = 30
+        desc = np.zeros((n, 2), np.int64); res = np.zeros((n, 3), np.int64)
+        for i in range(n):
+            bx, by = int(rng.integers(0, 192 - bw)), int(rng.integers(0, 136 - bh * k))
+            rx, ry = int(rng.integers(-40, 192 - bw - sw + 40)), int(rng.integers(-40, 136 - bh * k - sh + 40))
+            desc[i] = ((68 + by) * S + 68 + bx, (68 + ry) * S + 68 + rx)
+            res[i] = ref.sad_loop("SadLoopKernel", cur, int(desc[i, 0]), S * k, rf, int(desc[i, 1]), S * k, bh, bw, S, sw, sh)
+        out[f"sl_{name}_shape"] = np.array([bw, bh, sw, sh, k], np.int32)
+        out[f"sl_{name}_desc"] = desc
+        out[f"sl_{name}_res"] = res
+    np.savez_compressed(os.path.join(HERE, "pa_sadloop.npz"), **out)
+
+
 if __name__ == "__main__":
+    ois_fixture()
+    convolve_fixture()
+    pa_sadloop_fixture()
     quant_tables_fixture()
     fullpel209_fixture()
     transform_fixture()

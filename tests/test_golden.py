@@ -178,3 +178,140 @@ def test_hip_transforms_match_golden(hip_ctx):
         hip_ctx.synchronize()
         assert np.array_equal(d_c.cpu().numpy(), g[k + "coeff"]), (n, t)
         assert np.array_equal(d_rec.cpu().numpy().view(np.uint16).reshape(n, n), g[k + "rec"]), (n, t)
+
+
+# ---- round-2 components: open-loop intra search, AV1 convolutions, picture-analysis planes, SadLoopKernel ----
+def test_oracle_ois_matches_golden(oracle):
+    g = _load("ois.npz")
+    luma = g["luma"]
+    h, w = luma.shape
+    plane = np.ascontiguousarray(np.pad(luma, 68, mode="edge"))
+    for i in range(g["op"].shape[0]):
+        cand, total = oracle.ois_search_picture(plane, 68, w, h, g["op"][i], g["me"][i])
+        assert np.array_equal(cand, g["cand"][i]) and np.array_equal(total, g["total"][i]), i
+    for k, (cx, cy, s) in enumerate(g["pred_cus"]):
+        refs = oracle.ois_neighbours(plane, 68, w, h, int(cx), int(cy), int(s))
+        for mode in range(35):
+            assert np.array_equal(oracle.ois_predict(refs, int(s), mode), g["pred"][k, mode, :s, :s]), (k, mode)
+
+
+@pytest.mark.gpu
+def test_hip_ois_matches_golden(hip_ctx):
+    torch = pytest.importorskip("torch")
+    g = _load("ois.npz")
+    pic = synth.PaPicture(g["luma"])
+    w, h = pic.width, pic.height
+    pool, descs = svtav1_hip.build_picture_pool([pic])
+    sb = svtav1_hip.sb_origins(w, h)
+    n_sb = len(sb)
+    d_pool = torch.from_numpy(pool).to("cuda:0")
+    d_sb = torch.from_numpy(sb.view(np.int16)).to("cuda:0")
+    names = ["slice_is_intra", "temporal_layer_index", "is_used_as_reference_flag", "input_resolution_4k", "limit_ois_to_dc_mode_flag", "cu8x8_mode",
+             "enc_mode"]
+    for i in range(g["op"].shape[0]):
+        prm = svtav1_hip.OisParams()
+        for k, name in enumerate(names):
+            setattr(prm, name, int(g["op"][i][k]))
+        rows = np.zeros((n_sb, 85), svtav1_hip.ME_CU_RESULT_DTYPE)
+        rows["distortion"][:, :, 0] = g["me"][i]
+        d_me = torch.from_numpy(rows.view(np.uint8).reshape(-1)).to("cuda:0")
+        d_cand = torch.zeros(n_sb * 85 * 18, dtype=torch.int32, device="cuda:0")
+        d_total = torch.zeros(n_sb * 85, dtype=torch.uint8, device="cuda:0")
+        hip_ctx.open_loop_intra_search_batch_dev(d_pool.data_ptr(), descs, prm, d_sb.data_ptr(), n_sb, d_me.data_ptr(), 85, d_cand.data_ptr(),
+                                                 d_total.data_ptr())
+        hip_ctx.synchronize()
+        assert np.array_equal(d_cand.cpu().numpy().view(np.uint32).reshape(n_sb, 85, 18), g["cand"][i]), i
+        assert np.array_equal(d_total.cpu().numpy().reshape(n_sb, 85), g["total"][i]), i
+
+
+def _convolve_cases(g):
+    for key in g.files:
+        if key.startswith("desc_"):
+            w, h = (int(v) for v in key[5:].split("x"))
+            yield w, h, g[key], g[f"out_{w}x{h}"]
+
+
+def test_oracle_convolve_matches_golden(oracle):
+    import ctypes as C
+    g = _load("convolve.npz")
+    src = np.ascontiguousarray(g["src"])
+    S = src.shape[1]
+    f = oracle.lib.orc_av1_convolve_sr
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int]
+    for w, h, d, want in _convolve_cases(g):
+        for i in range(len(d)):
+            got = np.zeros((h, w), np.uint8)
+            f(src.ctypes.data + int(d[i, 1]) * S + int(d[i, 0]), S, got.ctypes.data, w, w, h, int(d[i, 4]), int(d[i, 5]), int(d[i, 2]), int(d[i, 3]))
+            assert np.array_equal(got, want[i]), (w, h, i)
+
+
+@pytest.mark.gpu
+def test_hip_convolve_matches_golden(hip_ctx):
+    torch = pytest.importorskip("torch")
+    g = _load("convolve.npz")
+    src = np.ascontiguousarray(g["src"])
+    S = src.shape[1]
+    d_src = torch.from_numpy(np.concatenate([src.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    for w, h, d, want in _convolve_cases(g):
+        n = len(d)
+        desc = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+        desc["src_offset"] = d[:, 1] * S + d[:, 0]
+        desc["dst_offset"] = np.arange(n) * w * h
+        desc["subpel_x"], desc["subpel_y"], desc["filter_x"], desc["filter_y"] = d[:, 2], d[:, 3], d[:, 4], d[:, 5]
+        # every block is its own w-wide strip of the destination: offsets i * w * h with stride w
+        d_dst = torch.zeros(n * w * h + 64, dtype=torch.uint8, device="cuda:0")
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        hip_ctx.av1_convolve_sr_batch_dev(d_src.data_ptr(), S, d_dst.data_ptr(), w, d_desc.data_ptr(), n, w, h)
+        hip_ctx.synchronize()
+        got = d_dst.cpu().numpy()[:n * w * h].reshape(n, h, w)
+        assert np.array_equal(got, want), (w, h)
+
+
+def test_oracle_pa_planes_and_sad_loop_match_golden(oracle):
+    g = _load("pa_sadloop.npz")
+    full, quarter, sixteenth = oracle.pa_derive_planes(g["luma"])
+    assert np.array_equal(full, g["full"]) and np.array_equal(quarter, g["quarter"]) and np.array_equal(sixteenth, g["sixteenth"])
+    cur, ref = synth.PaPicture(g["sl_cur"]).full, synth.PaPicture(g["sl_ref"]).full
+    S = cur.shape[1]
+    for name in "abc":
+        bw, bh, sw, sh, k = (int(v) for v in g[f"sl_{name}_shape"])
+        for (so, ro), want in zip(g[f"sl_{name}_desc"], g[f"sl_{name}_res"]):
+            assert oracle.sad_loop(cur, int(so), S * k, ref, int(ro), S * k, bh, bw, S, sw, sh) == tuple(int(v) for v in want)
+
+
+@pytest.mark.gpu
+def test_hip_pa_planes_and_sad_loop_match_golden(hip_ctx):
+    torch = pytest.importorskip("torch")
+    g = _load("pa_sadloop.npz")
+    pic = synth.PaPicture(g["luma"])
+    pool, descs = svtav1_hip.build_picture_pool([pic])
+    raw = np.full_like(pool, 0xEE)
+    d = descs[0]
+    fs = d.full_stride
+    plane = raw[d.full_offset:d.full_offset + fs * (pic.height + 136)].reshape(pic.height + 136, fs)
+    plane[68:68 + pic.height, 68:68 + pic.width] = g["luma"]
+    d_pool = torch.from_numpy(raw).to("cuda:0")
+    hip_ctx.pa_derive_planes_dev(d_pool.data_ptr(), descs)
+    hip_ctx.synchronize()
+    got = d_pool.cpu().numpy()
+    for name in ("full", "quarter", "sixteenth"):
+        off = getattr(d, name + "_offset")
+        assert np.array_equal(got[off:off + g[name].size].reshape(g[name].shape), g[name]), name
+    cur, ref = synth.PaPicture(g["sl_cur"]).full, synth.PaPicture(g["sl_ref"]).full
+    S = cur.shape[1]
+    d_cur = torch.from_numpy(np.concatenate([cur.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d_ref = torch.from_numpy(np.concatenate([ref.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    for name in "abc":
+        bw, bh, sw, sh, k = (int(v) for v in g[f"sl_{name}_shape"])
+        desc = g[f"sl_{name}_desc"].astype(np.uint32)
+        n = len(desc)
+        d_desc = torch.from_numpy(desc.view(np.int32).reshape(-1).copy()).to("cuda:0")
+        d_sad = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        d_xy = torch.zeros(2 * n, dtype=torch.int16, device="cuda:0")
+        hip_ctx.sad_loop_batch_dev(d_cur.data_ptr(), S * k, d_ref.data_ptr(), S * k, S, d_desc.data_ptr(), n, bw, bh, sw, sh, d_sad.data_ptr(),
+                                   d_xy.data_ptr())
+        hip_ctx.synchronize()
+        want = g[f"sl_{name}_res"]
+        assert np.array_equal(d_sad.cpu().numpy().astype(np.int64), want[:, 0]), name
+        assert np.array_equal(d_xy.cpu().numpy().reshape(n, 2).astype(np.int64), want[:, 1:3]), name
