@@ -602,6 +602,15 @@ int32_t svthip_open_loop_intra_search_batch_dev(svthip_ctx *ctx, const uint8_t *
                                                 const svthip_sb_origin *d_sb, uint32_t n_sb, const svthip_me_cu_result *d_me,
                                                 uint32_t me_pu_stride, uint32_t *d_cand, uint8_t *d_total, void *stream);
 
+/* OpenLoopIntraSearchLcu for every SB of one picture with HOST buffers (the second SB loop of MotionEstimationKernel,
+ * Codec/EbMotionEstimationProcess.c:558-579): uploads the luma interior (any origin: the search never reads outside the picture),
+ * takes distortionDirection[0].distortion of entries 0..84 of every SB's me_results row (me_results[sb] -> MeCuResults_t[n_pu],
+ * host memory, 40-byte layout above; may be NULL on the branches that do not read it), runs
+ * svthip_open_loop_intra_search_batch_dev and returns cand [n_sb][85][18] / total [n_sb][85] in host memory.  Synchronous. */
+int32_t svthip_open_loop_intra_search_picture(svthip_ctx *ctx, const svthip_host_picture *cur, const svthip_ois_params *params,
+                                              const void *const *me_results, uint32_t n_pu, uint32_t *cand, uint8_t *total);
+
+
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */
 int32_t svthip_me_fullpel_search_time_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,

@@ -853,6 +853,72 @@ int32_t svthip_motion_estimate_picture(svthip_ctx* ctx, const svthip_host_pictur
     return SVTHIP_OK;
 }
 
+int32_t svthip_open_loop_intra_search_picture(svthip_ctx* ctx, const svthip_host_picture* cur, const svthip_ois_params* params,
+                                              const void* const* me_results, uint32_t n_pu, uint32_t* cand, uint8_t* total)
+{
+    ENTER(ctx);
+    if (!cur || !params || !cand || !total || !cur->buffer_y) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    const uint32_t w = cur->width, h = cur->height;
+    if ((w & 7) || (h & 7) || !w || !h) return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be non-zero multiples of 8%s", "");
+    if (cur->stride_y < w + cur->origin_x) return fail(SVTHIP_ERR_BAD_PARAMETER, "stride smaller than origin_x + width%s", "");
+    const bool general = !params->slice_is_intra && !(params->temporal_layer_index == 0 && !params->input_resolution_4k) &&
+                         !params->limit_ois_to_dc_mode_flag;
+    if (general && (!me_results || (n_pu != 85 && n_pu != 209)))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "this picture's branch reads me_results (n_pu 85 or 209)%s (n_pu %d)", "", (int)n_pu);
+    const uint32_t fs = w + 136, nx = (w + 63) / 64, ny = (h + 63) / 64, n_sb = nx * ny;
+    const size_t cand_bytes = (size_t)n_sb * 85 * 18 * 4, total_bytes = (size_t)n_sb * 85;
+    int32_t rc;
+    if ((rc = ensure_scratch(ctx, 8, (size_t)fs * (h + 136) + 256))) return rc;
+    if ((rc = ensure_scratch(ctx, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
+    if ((rc = ensure_scratch(ctx, 10, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85))) return rc;
+    if ((rc = ensure_scratch(ctx, 11, cand_bytes + total_bytes))) return rc;
+    hipStream_t s = ctx->stream;
+    if ((rc = scratch_on_stream(ctx, s))) return rc;
+    uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
+    // only the picture interior is ever read by the search (samples outside the picture count as 128): any origin is accepted
+    HIP_TRY(hipMemcpy2DAsync(pool + (size_t)68 * fs + 68, fs, cur->buffer_y + (size_t)cur->origin_y * cur->stride_y + cur->origin_x, cur->stride_y, w, h,
+                             hipMemcpyHostToDevice, s));
+    svthip_sb_origin* sbs = new (std::nothrow) svthip_sb_origin[n_sb];
+    svthip_me_cu_result* rows = general ? new (std::nothrow) svthip_me_cu_result[(size_t)n_sb * 85] : nullptr;
+    if (!sbs || (general && !rows)) {
+        delete[] sbs;
+        delete[] rows;
+        return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
+    }
+    for (uint32_t y = 0; y < ny; y++)
+        for (uint32_t x = 0; x < nx; x++) sbs[y * nx + x] = svthip_sb_origin{(uint16_t)(x * 64), (uint16_t)(y * 64)};
+    hipError_t e = hipSuccess;
+    if (general) {
+        memset(rows, 0, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85);
+        for (uint32_t i = 0; i < n_sb && e == hipSuccess; i++) {
+            if (!me_results[i]) { e = hipErrorInvalidValue; break; }
+            const svthip_me_cu_result_ref* r = static_cast<const svthip_me_cu_result_ref*>(me_results[i]);
+            for (uint32_t cu = 0; cu < 85; cu++) rows[(size_t)i * 85 + cu].distortion[0] = r[cu].distortionDirection[0].distortion;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->scratch[10], rows, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85, hipMemcpyHostToDevice, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->scratch[9], sbs, sizeof(svthip_sb_origin) * n_sb, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the staging arrays are pageable: the copies have left them before they are freed
+    delete[] sbs;
+    delete[] rows;
+    if (e == hipErrorInvalidValue) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results row pointer is null%s", "");
+    HIP_TRY(e);
+    svthip_pa_picture pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.full_stride = fs;
+    pd.width = (uint16_t)w;
+    pd.height = (uint16_t)h;
+    uint32_t* d_cand = static_cast<uint32_t*>(ctx->scratch[11]);
+    uint8_t* d_total = static_cast<uint8_t*>(ctx->scratch[11]) + cand_bytes;
+    if ((rc = svthip_open_loop_intra_search_batch_dev(ctx, pool, &pd, 1, params, static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb,
+                                                      general ? static_cast<const svthip_me_cu_result*>(ctx->scratch[10]) : nullptr, 85, d_cand, d_total, s)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(cand, d_cand, cand_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(total, d_total, total_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return SVTHIP_OK;
+}
+
 int32_t svthip_encode_tu_batch(svthip_ctx* ctx, const void* src, const void* pred, void* recon, size_t plane_samples, int32_t planes_16bit,
                                const svthip_tu_desc* desc, uint32_t n_tu, uint32_t tx_width, uint32_t tx_height, const int16_t* qparams,
                                uint32_t n_qparam_rows, const int16_t* iscan, uint32_t n_iscan, size_t coeff_samples, int32_t* coeff,

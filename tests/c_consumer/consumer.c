@@ -3,7 +3,7 @@
  * the reference's C code would be (gcc -std=c99, no C++), linked to libsvtav1_hip.so.  It is the only consumer of the header that is
  * not the ctypes mirror, so it pins the struct layouts (_Static_assert) and drives the host-pointer surface end to end:
  *   create -> full-pel search (host pointers) -> whole-picture ME into MeCuResults_t-layout rows -> fused TU chain (host pointers) ->
- *   RTCD same-signature shims -> two threads x two contexts with different search areas -> destroy.
+ *   open-loop intra search from host rows -> RTCD same-signature shims -> two threads x two contexts with different search areas -> destroy.
  * Inputs come from a file written by tests/test_c_consumer.py, outputs go to a file the test compares with the oracle.
  *
  *   consumer <in.bin> <out.bin>        sections: [u32 tag][u32 pad][u64 bytes][payload]
@@ -58,7 +58,7 @@ enum {
     TAG_DIMS = 1, TAG_CUR, TAG_REF0, TAG_REF1, TAG_PARAMS, TAG_FP_DESC, TAG_TU_SRC, TAG_TU_PRED, TAG_TU_DESC, TAG_TU_QP, TAG_TU_ISCAN, TAG_TU_DIMS,
     TAG_TX_RES, TAG_TX_COEFFQ, TAG_TX_QROW, TAG_TX_SCAN, TAG_TX_ISCAN, TAG_TX_PRED, TAG_FP_DESC_SMALL,
     OUT_FP_SAD = 100, OUT_FP_MV, OUT_ME, OUT_TU_RECON, OUT_TU_Q, OUT_TU_EOB, OUT_TX_FWD, OUT_TX_INV, OUT_TX_Q, OUT_TX_DQ, OUT_TX_EOB, OUT_THREADS,
-    OUT_TU_DIST, OUT_ME209
+    OUT_TU_DIST, OUT_ME209, OUT_OIS_GEN_CAND, OUT_OIS_GEN_TOTAL, OUT_OIS_I_CAND, OUT_OIS_I_TOTAL
 };
 
 typedef struct { uint32_t tag; uint64_t bytes; void *data; } Section;
@@ -187,6 +187,30 @@ int main(int argc, char **argv)
                 o[10] = r->totalMeCandidateIndex;
             }
         put(fo, pass ? OUT_ME209 : OUT_ME, flat, (uint64_t)sizeof(int32_t) * 11 * n_pu * nsb);
+        if (pass == 0) {
+            /* 2b. the ME process's second loop: open-loop intra search from the same host picture and the host's MeCuResults_t rows
+             *     (general branch), and once more as an intra picture (no ME rows needed) */
+            uint32_t *cand = (uint32_t *)malloc((size_t)nsb * 85 * 18 * 4);
+            uint8_t *total = (uint8_t *)malloc((size_t)nsb * 85);
+            svthip_ois_params op;
+            memset(&op, 0, sizeof(op));
+            op.temporal_layer_index = 2;
+            op.is_used_as_reference_flag = 1;
+            CHECK(svthip_open_loop_intra_search_picture(ctx, &pc, &op, (const void *const *)rows, n_pu, cand, total));
+            put(fo, OUT_OIS_GEN_CAND, cand, (uint64_t)nsb * 85 * 18 * 4);
+            put(fo, OUT_OIS_GEN_TOTAL, total, (uint64_t)nsb * 85);
+            if (svthip_open_loop_intra_search_picture(ctx, &pc, &op, NULL, n_pu, cand, total) != SVTHIP_ERR_BAD_PARAMETER) {
+                fprintf(stderr, "consumer: missing me_results on the general branch was not rejected\n");
+                return 5;
+            }
+            memset(&op, 0, sizeof(op));
+            op.slice_is_intra = 1;
+            CHECK(svthip_open_loop_intra_search_picture(ctx, &pc, &op, NULL, 0, cand, total));
+            put(fo, OUT_OIS_I_CAND, cand, (uint64_t)nsb * 85 * 18 * 4);
+            put(fo, OUT_OIS_I_TOTAL, total, (uint64_t)nsb * 85);
+            free(cand);
+            free(total);
+        }
         for (uint32_t i = 0; i < nsb; i++) free(rows[i]);
         free(rows);
         free(flat);

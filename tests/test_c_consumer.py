@@ -19,7 +19,7 @@ EXE = os.path.join(CDIR, "consumer")
 T = dict(DIMS=1, CUR=2, REF0=3, REF1=4, PARAMS=5, FP_DESC=6, TU_SRC=7, TU_PRED=8, TU_DESC=9, TU_QP=10, TU_ISCAN=11, TU_DIMS=12, TX_RES=13,
          TX_COEFFQ=14, TX_QROW=15, TX_SCAN=16, TX_ISCAN=17, TX_PRED=18, FP_DESC_SMALL=19)
 O = dict(FP_SAD=100, FP_MV=101, ME=102, TU_RECON=103, TU_Q=104, TU_EOB=105, TX_FWD=106, TX_INV=107, TX_Q=108, TX_DQ=109, TX_EOB=110, THREADS=111,
-         TU_DIST=112, ME209=113)
+         TU_DIST=112, ME209=113, OIS_GEN_CAND=114, OIS_GEN_TOTAL=115, OIS_I_CAND=116, OIS_I_TOTAL=117)
 
 
 def test_header_compiles_as_c99_and_layouts_hold():
@@ -98,6 +98,17 @@ def test_c_consumer_end_to_end(tmp_path, oracle):
         assert np.array_equal(flat[:, :, 2], want["xMvL1"]) and np.array_equal(flat[:, :, 3], want["yMvL1"])
         assert np.array_equal(flat[:, :, 4:7].astype(np.uint32), want["distortion"]) and np.array_equal(flat[:, :, 7:10], want["direction"])
         assert np.array_equal(flat[:, :, 10], want["totalMeCandidateIndex"])
+        if n_pu == 85:   # 2b. open-loop intra search fed from the host's MeCuResults_t rows (general branch) and as an intra picture
+            n_sb = want["distortion"].shape[0]
+            op = np.zeros(7, np.int32); op[1] = 2; op[2] = 1
+            wc, wt = oracle.ois_search_picture(pics[0].full, 68, w, h, op, want["distortion"][:, :85, 0])
+            assert np.array_equal(np.frombuffer(got[O["OIS_GEN_CAND"]], np.uint32).reshape(n_sb, 85, 18), wc)
+            assert np.array_equal(np.frombuffer(got[O["OIS_GEN_TOTAL"]], np.uint8).reshape(n_sb, 85), wt)
+            assert len(np.unique(wt)) >= 2
+            op = np.zeros(7, np.int32); op[0] = 1
+            wc, wt = oracle.ois_search_picture(pics[0].full, 68, w, h, op, None)
+            assert np.array_equal(np.frombuffer(got[O["OIS_I_CAND"]], np.uint32).reshape(n_sb, 85, 18), wc)
+            assert np.array_equal(np.frombuffer(got[O["OIS_I_TOTAL"]], np.uint8).reshape(n_sb, 85), wt)
     # 3. fused TU chain, host pointers
     want = oracle_encode_batch(oracle, tb)
     assert np.array_equal(np.frombuffer(got[O["TU_RECON"]], np.uint8), want["recon"])
