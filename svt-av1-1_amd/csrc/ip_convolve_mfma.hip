@@ -1,0 +1,186 @@
+// svt-av1-1_amd/csrc/ip_convolve_mfma.hip
+//
+// AV1 single-reference inter prediction of blocks whose sides are multiples of 32, on the matrix cores (gfx950) -- bit-exact.
+// Same contract as av1_convolve_sr_kernel (ip_convolve.hip): av1_convolve_2d_sr / _x_sr / _y_sr / _2d_copy_sr
+// (reference: Source/Lib/Codec/EbInterPrediction.c:145-286), kernels by av1_get_interp_filter_params_with_block_size (:985-995),
+// rounding of get_conv_params_no_round (round_0 = 3, round_1 = 11).
+//
+// Unlike the transforms, the interpolation IS a dense integer contraction: each pass is a sum of tap x sample
+// products with ONE rounding at its end, so a pass is a product with a banded (Toeplitz) tap matrix and v_mfma_i32_32x32x32_i8
+// computes it exactly.
+//   pass 1   IM[r][n] = (sum_k f[k] (p[r][n + k] - 128) + C1) >> S1       A = samples (rows on lanes), B = Tx[k][n] = f[k - n]
+//   pass 2   OUT[y][n] = clip((sum_k g[k] IM[y + k][n] + C2) >> S2)       A = Ty[y][k] = g[k - y],     B = IM
+// IM is 13 bits and non-negative (the reference's 1 << 14 offset), so it is split into two i8 digits IM = 128 hi + lo and pass 2 is two
+// products.  The accumulator tile of pass 1 (column on the lane, rows in the registers) IS the B operand of pass 2 -- the sum runs over
+// IM's row index -- so nothing goes through LDS: the k order of Ty's fragment is permuted to the tile's row order
+// (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand").  x-only / y-only / copy blocks use a unit tap for the
+// missing pass and the reference's own constants for that case, so one code path serves all four functions.
+//
+// One wave per 32-column x 64-row piece of a block (two output tiles sharing the IM tile between them; 32 rows when the height is not a
+// multiple of 64): 39 x 71 samples in, three 32-row IM tiles (71 rows used), 6 + 8 MFMAs.  Reads stay inside the API's window: 3 samples left / above and 4 (+ at most 9 more bytes to the right) right / below,
+// and only when the respective phase is non-zero.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/svtav1_hip.h"
+#include "me_kernels.h"
+
+namespace svthip {
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ const uint32_t kInterpM[6][16][2] =
+#include "av1_interp_filters.inc"
+    ;
+
+// bytes [s, s + 8) of the sequence (.. 0, t0 .. t7, 0 ..) whose bytes 0..7 are T
+__device__ __forceinline__ uint64_t seq8(uint64_t T, int s)
+{
+    if (s >= 8 || s <= -8) return 0;
+    return s >= 0 ? (T >> (8 * s)) : (T << (-8 * s));
+}
+
+// bytes [s, s + 4) of the same sequence
+__device__ __forceinline__ uint32_t seq4(uint64_t T, int s)
+{
+    if (s >= 8 || s <= -4) return 0;
+    return s >= 0 ? (uint32_t)(T >> (8 * s)) : ((uint32_t)T << (-8 * s));
+}
+
+}  // namespace
+
+// TY = output tiles stacked vertically per wave: they share the IM tile between them (TY + 1 IM tiles instead of 2 TY) and the tap fragments
+template <int TY>
+__global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, uint8_t* __restrict__ dst,
+                                                                   uint32_t dst_stride, const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h)
+{
+    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
+    const int tiles_x = w >> 5, tiles = tiles_x * (h / (32 * TY));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t b = wave / (uint32_t)tiles;
+    if (b >= n_blocks) return;
+    const int t = (int)(wave - b * (uint32_t)tiles), ty = t / tiles_x, tx = t - ty * tiles_x;
+    const uint4 d = desc[b];
+    const int sx = d.z & 15, sy = (d.z >> 8) & 15;
+    // taps as 8 packed signed bytes; a missing pass is the unit tap at k = 0 on an unshifted window
+    uint64_t F = 1, G = 1;
+    if (sx) F = ((uint64_t)kInterpM[(d.z >> 16) & 255][sx][1] << 32) | kInterpM[(d.z >> 16) & 255][sx][0];
+    if (sy) G = ((uint64_t)kInterpM[(d.z >> 24) & 255][sy][1] << 32) | kInterpM[(d.z >> 24) & 255][sy][0];
+    const int c0 = sx ? -3 : 0, r0 = sy ? -3 : 0;
+    const int rows_needed = 32 * TY + (sy ? 7 : 0), n_kx = sx ? 2 : 1, n_im = TY + (sy ? 1 : 0), n_e = sy ? 2 : 1;
+    const int C1 = sx ? 32768 + 4 : 128, S1 = sx ? 3 : 0;
+    const int C2 = sx ? (sy ? -261120 : -2040) : (sy ? 64 : 0), S2 = sx ? (sy ? 11 : 4) : (sy ? 7 : 0);
+    const uint8_t* base = src + d.x + (int64_t)(32 * TY * ty + r0) * src_stride + 32 * tx + c0;
+
+    // Tx fragments: element j of lane half hh is k = 16 hh + j of column chunk c; coefficient f[k + 32 c - n]
+    v4i bx[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int s = 16 * hh + 32 * c - n;
+        const uint64_t lo = seq8(F, s), hi = seq8(F, s + 8);
+        bx[c] = v4i{(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
+    }
+    // Ty fragments by IM-tile distance e = 0 (same tile) / 1 (next tile): element j <-> IM row 32 e + (j & 3) + 8 (j >> 2) + 4 hh; coefficient
+    // g[row - y], y = n
+    v4i ay[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ay[e][q] = (int)seq4(G, 32 * e + 8 * q + 4 * hh - n);
+
+    // all sample fragments are requested up front (one memory latency per wave), then the IM tiles are worked through one at a time
+    v4i a_frag[TY + 1][2];
+#pragma unroll
+    for (int it = 0; it < TY + 1; it++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            a_frag[it][c] = v4i{0, 0, 0, 0};
+            const int R = 32 * it + n;  // this lane's sample row of the A fragment
+            if (it < n_im && c < n_kx && R < rows_needed && (c == 0 || hh == 0)) {
+                uint4 raw;
+                __builtin_memcpy(&raw, base + (int64_t)R * src_stride + 32 * c + 16 * hh, 16);
+                a_frag[it][c] = v4i{(int)raw.x, (int)raw.y, (int)raw.z, (int)raw.w};
+            }
+        }
+    // IM tiles -> packed i8 digit fragments (element j = accumulator register j = IM row (j & 3) + 8 (j >> 2) + 4 hh of the tile)
+    v4i im_hi[TY + 1], im_lo[TY + 1];
+#pragma unroll
+    for (int it = 0; it < TY + 1; it++) {
+        __builtin_amdgcn_sched_barrier(0);  // one accumulator tile live at a time
+        if (it < n_im) {
+            v16i acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = C1;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (c < n_kx) {
+                    const v4i a = a_frag[it][c] ^ (int)0x80808080;  // samples - 128 as signed bytes (zero fragments become -128 against zero taps)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bx[c], acc, 0, 0, 0);
+                }
+            }
+            uint32_t ph[4], pl[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // two 13-bit values per dword, then the digits of both, then four bytes per dword
+                const uint32_t v01 = (uint32_t)(acc[4 * q] >> S1) | ((uint32_t)(acc[4 * q + 1] >> S1) << 16);
+                const uint32_t v23 = (uint32_t)(acc[4 * q + 2] >> S1) | ((uint32_t)(acc[4 * q + 3] >> S1) << 16);
+                const uint32_t l01 = v01 & 0x007f007fu, l23 = v23 & 0x007f007fu, h01 = (v01 >> 7) & 0x007f007fu, h23 = (v23 >> 7) & 0x007f007fu;
+                pl[q] = __builtin_amdgcn_perm(l23, l01, 0x06040200u);
+                ph[q] = __builtin_amdgcn_perm(h23, h01, 0x06040200u);
+            }
+            im_lo[it] = v4i{(int)pl[0], (int)pl[1], (int)pl[2], (int)pl[3]};
+            im_hi[it] = v4i{(int)ph[0], (int)ph[1], (int)ph[2], (int)ph[3]};
+        }
+    }
+    // pass 2 per output tile: A = Ty, B = IM digits (column x on the lane): the result keeps the column on the lane, so a store instruction
+    // writes two whole 32-byte row segments (the transposed form, four pixels per lane, scatters 4-byte pieces over 32 rows and measured slower)
+#pragma unroll
+    for (int ot = 0; ot < TY; ot++) {
+        __builtin_amdgcn_sched_barrier(0);  // one output tile's accumulators at a time (the scheduler interleaves them: 64 AGPRs, 3 waves / SIMD)
+        v16i olo, ohi;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            olo[i] = C2;
+            ohi[i] = 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (e < n_e) {
+                olo = __builtin_amdgcn_mfma_i32_32x32x32_i8(ay[e], im_lo[ot + e], olo, 0, 0, 0);
+                ohi = __builtin_amdgcn_mfma_i32_32x32x32_i8(ay[e], im_hi[ot + e], ohi, 0, 0, 0);
+            }
+        }
+        uint8_t* o = dst + d.y + (int64_t)(32 * (TY * ty + ot) + 4 * hh) * dst_stride + 32 * tx + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            int v = ((ohi[reg] << 7) + olo[reg]) >> S2;
+            // shift-then-clip of two neighbours can be fused into v_ashr_pk_u8_i32, whose result did not match the C semantics (gfx950, ROCm 7.2;
+            // same finding as me_subpel_common.h::hfilt1): keep the shifted value opaque
+            asm volatile("" : "+v"(v));
+            v = v < 0 ? 0 : v > 255 ? 255 : v;
+            o[(int64_t)((reg & 3) + 8 * (reg >> 2)) * dst_stride] = (uint8_t)v;
+        }
+    }
+}
+
+bool convolve_mfma_size_valid(int w, int h) { return (w & 31) == 0 && (h & 31) == 0 && w >= 32 && h >= 32 && w <= 128 && h <= 128; }
+
+hipError_t launch_av1_convolve_sr_mfma(const uint8_t* src, uint32_t src_stride, uint8_t* dst, uint32_t dst_stride, const svthip_convolve_desc* desc,
+                                       uint32_t n_blocks, int w, int h, hipStream_t s)
+{
+    const int ty = (h & 63) == 0 ? 2 : 1;
+    const uint64_t waves = (uint64_t)n_blocks * (uint32_t)((w >> 5) * (h / (32 * ty)));
+    const dim3 grid((uint32_t)((waves + 3) / 4)), block(256);
+    if (ty == 2)
+        hipLaunchKernelGGL(av1_convolve_sr_mfma_kernel<2>, grid, block, 0, s, src, src_stride, dst, dst_stride, reinterpret_cast<const uint4*>(desc),
+                           n_blocks, w, h);
+    else
+        hipLaunchKernelGGL(av1_convolve_sr_mfma_kernel<1>, grid, block, 0, s, src, src_stride, dst, dst_stride, reinterpret_cast<const uint4*>(desc),
+                           n_blocks, w, h);
+    return hipGetLastError();
+}
+
+}  // namespace svthip

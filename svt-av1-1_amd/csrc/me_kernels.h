@@ -113,6 +113,9 @@ size_t fullpel209_lds_bytes(uint32_t max_sh);
 __global__ void sad_loop_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, const uint8_t* __restrict__ ref, uint32_t ref_stride,
                                 uint32_t ref_stride_raw, const svthip_sad_loop_desc* __restrict__ desc, uint32_t n_blocks, int w, int h, int sw, int sh,
                                 int slice_bytes, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy);
+bool convolve_mfma_size_valid(int w, int h);
+hipError_t launch_av1_convolve_sr_mfma(const uint8_t* src, uint32_t src_stride, uint8_t* dst, uint32_t dst_stride, const svthip_convolve_desc* desc,
+                                       uint32_t n_blocks, int w, int h, hipStream_t s);
 size_t sad_loop_qsad_slice_bytes(int w, int h, int sw, int sh, int k);
 hipError_t launch_sad_loop_qsad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t ref_stride_raw,
                                 const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, int slice_bytes,

@@ -737,6 +737,11 @@ int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, 
     if (!d_src || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (reinterpret_cast<uintptr_t>(d_desc) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !getenv("SVTHIP_CONVOLVE_VALU")) {
+        // sides that are multiples of 32: both passes as exact i8 matrix products on the matrix cores (ip_convolve_mfma.hip)
+        HIP_TRY(svthip::launch_av1_convolve_sr_mfma(d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
+        return SVTHIP_OK;
+    }
     HIP_TRY(svthip::launch_av1_convolve_sr(d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
     return SVTHIP_OK;
 }
