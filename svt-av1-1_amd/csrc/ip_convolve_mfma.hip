@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
     const int rows_needed = 32 * TY + (sy ? 7 : 0), n_kx = sx ? 2 : 1, n_im = TY + (sy ? 1 : 0), n_e = sy ? 2 : 1;
     const int C1 = sx ? 32768 + 4 : 128, S1 = sx ? 3 : 0;
     const int C2 = sx ? (sy ? -261120 : -2040) : (sy ? 64 : 0), S2 = sx ? (sy ? 11 : 4) : (sy ? 7 : 0);
-    const uint8_t* base = src + d.x + (int64_t)(32 * TY * ty + r0) * src_stride + 32 * tx + c0;
+    // 32-bit offsets from the (uniform) plane pointers: one VALU add per access instead of 64-bit pointer arithmetic
+    const uint32_t base = d.x + (uint32_t)((32 * TY * ty + r0) * (int)src_stride + 32 * tx + c0);
 
     // Tx fragments: element j of lane half hh is k = 16 hh + j of column chunk c; coefficient f[k + 32 c - n]
     v4i bx[2];
@@ -83,6 +84,9 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
         const uint64_t lo = seq8(F, s), hi = seq8(F, s + 8);
         bx[c] = v4i{(int)(uint32_t)lo, (int)(uint32_t)(lo >> 32), (int)(uint32_t)hi, (int)(uint32_t)(hi >> 32)};
     }
+    // Bias of pass 1 without touching the accumulators: the k slots of chunk 1, lane half 1 meet only zero taps.  Their sample bytes are set to
+    // (127, 127, 127, 1) after the -128 offset and their "taps" to (127, 127, 4, 6): 127 * 127 * 2 + 127 * 4 + 6 = 32768 + 4 = C1.
+    if (sx && hh == 1) bx[1] = v4i{(int)0x06047f7fu, 0, 0, 0};
     // Ty fragments by IM-tile distance e = 0 (same tile) / 1 (next tile): element j <-> IM row 32 e + (j & 3) + 8 (j >> 2) + 4 hh; coefficient
     // g[row - y], y = n
     v4i ay[2];
@@ -97,11 +101,11 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
     for (int it = 0; it < TY + 1; it++)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            a_frag[it][c] = v4i{0, 0, 0, 0};
+            a_frag[it][c] = (c == 1 && hh == 1) ? v4i{(int)0x81ffffffu, 0, 0, 0} : v4i{0, 0, 0, 0};  // bias slots (see bx[1])
             const int R = 32 * it + n;  // this lane's sample row of the A fragment
             if (it < n_im && c < n_kx && R < rows_needed && (c == 0 || hh == 0)) {
                 uint4 raw;
-                __builtin_memcpy(&raw, base + (int64_t)R * src_stride + 32 * c + 16 * hh, 16);
+                __builtin_memcpy(&raw, src + (base + (uint32_t)R * src_stride + (uint32_t)(32 * c + 16 * hh)), 16);
                 a_frag[it][c] = v4i{(int)raw.x, (int)raw.y, (int)raw.z, (int)raw.w};
             }
         }
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
         if (it < n_im) {
             v16i acc;
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[i] = C1;
+            for (int i = 0; i < 16; i++) acc[i] = sx ? 0 : C1;  // with a horizontal filter the bias rides in four spare k slots (below)
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 if (c < n_kx) {
@@ -153,7 +157,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
                 ohi = __builtin_amdgcn_mfma_i32_32x32x32_i8(ay[e], im_hi[ot + e], ohi, 0, 0, 0);
             }
         }
-        uint8_t* o = dst + d.y + (int64_t)(32 * (TY * ty + ot) + 4 * hh) * dst_stride + 32 * tx + n;
+        const uint32_t o = d.y + (uint32_t)(32 * (TY * ty + ot) + 4 * hh) * dst_stride + (uint32_t)(32 * tx + n);
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             int v = ((ohi[reg] << 7) + olo[reg]) >> S2;
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
             // same finding as me_subpel_common.h::hfilt1): keep the shifted value opaque
             asm volatile("" : "+v"(v));
             v = v < 0 ? 0 : v > 255 ? 255 : v;
-            o[(int64_t)((reg & 3) + 8 * (reg >> 2)) * dst_stride] = (uint8_t)v;
+            dst[o + (uint32_t)((reg & 3) + 8 * (reg >> 2)) * dst_stride] = (uint8_t)v;
         }
     }
 }

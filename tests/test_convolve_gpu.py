@@ -57,6 +57,14 @@ def test_convolve_every_block_size(hip_ctx, oracle, size):
     got = _run(hip_ctx, src, S, dst, D, desc, w, h)
     bad = np.argwhere(got != want)
     assert bad.size == 0, (size, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+    if w % 32 == 0 and h % 32 == 0:   # these sizes run on the matrix cores; the VALU kernel must agree on them as well
+        import os
+        os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+        try:
+            got2 = _run(hip_ctx, src, S, dst, D, desc, w, h)
+        finally:
+            del os.environ["SVTHIP_CONVOLVE_VALU"]
+        assert np.array_equal(got2, want), size
 
 
 def test_convolve_64x64_all_phases_1080p(hip_ctx, oracle):
