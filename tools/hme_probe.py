@@ -6,12 +6,11 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "svt-av1-1_amd",
 import numpy as np, torch
 import svtav1_hip, bench
 
-pool, stride, desc, pdesc = bench.build_pool(12, 0)
 dev = torch.device("cuda:0")
-d_pool = torch.from_numpy(pool).to(dev)
-d_desc = torch.from_numpy(desc).to(dev)
-d_sb = torch.from_numpy(svtav1_hip.sb_origins(1920, 1080).view(np.int16).copy()).to(dev)
 ctx = svtav1_hip.Context(0)
+d_pool, pdesc = bench.device_picture_pool(ctx, 13, 1920, 1080, dev)
+d_desc = torch.zeros(12 * 510 * 6, dtype=torch.int32, device=dev)
+d_sb = torch.from_numpy(svtav1_hip.sb_origins(1920, 1080).view(np.int16).copy()).to(dev)
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
 curs = [pdesc[i + 1] for i in range(12)]; refs = [pdesc[i] for i in range(12)]
 for name, flags in (("all levels", (1, 1, 1, 1)), ("L0 + L1", (1, 1, 1, 0)), ("L0 only", (1, 1, 0, 0)), ("centre check only", (0, 0, 0, 0))):
