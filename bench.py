@@ -343,9 +343,24 @@ def leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev):
     d_dst = torch.empty(n * 4096, dtype=torch.uint8, device=dev)
     ms = timer.ms(lambda: ctx.av1_convolve_sr_batch_dev(pool.data_ptr(), S, d_dst.data_ptr(), 64, d_desc.data_ptr(), n, 64, 64, timer.stream), 10)
     algo = n * (71 * 71 + 4096 + 16)
-    return {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
-            "frac_hbm": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4),
-            "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per block"}
+    out = {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
+           "frac_hbm": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4),
+           "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per block"}
+    # the BI_PRED form of the same blocks: list 0 from picture 1, list 1 from picture 2 with the phases swapped (av1_jnt_convolve_2d pair)
+    c = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+    c["src0_offset"] = d["src_offset"]
+    c["src1_offset"] = pdesc[2].full_offset + (68 + (blk // nbx) * 64) * S + 68 + (blk % nbx) * 64
+    c["dst_offset"] = d["dst_offset"]
+    c["subpel0"] = d["subpel_x"] | (d["subpel_y"] << 4)
+    c["subpel1"] = d["subpel_y"] | (d["subpel_x"] << 4)
+    c["filter_x"], c["filter_y"] = d["filter_x"], d["filter_y"]
+    d_cdesc = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).to(dev)
+    msc = timer.ms(lambda: ctx.av1_convolve_compound_batch_dev(pool.data_ptr(), S, pool.data_ptr(), S, d_dst.data_ptr(), 64, d_cdesc.data_ptr(), n, 64, 64,
+                                                               timer.stream), 10)
+    algoc = n * (2 * 71 * 71 + 4096 + 16)
+    out["compound_bipred"] = {"ms": round(msc, 4), "gpix_per_s": round(n * 4096 / msc / 1e6, 2), "algorithmic_gbps": round(algoc / msc / 1e6, 1),
+                              "frac_hbm": round(algoc / msc / 1e6 / HBM_PEAK_GBPS, 4)}
+    return out
 
 
 def leg_sad_loop(ctx, torch, svtav1_hip, timer, dev):

@@ -474,6 +474,27 @@ typedef struct svthip_convolve_desc {
 int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx *ctx, const uint8_t *d_src, uint32_t src_stride, uint8_t *d_dst, uint32_t dst_stride,
                                          const svthip_convolve_desc *d_desc, uint32_t n_blocks, uint32_t width, uint32_t height, void *stream);
 
+/* The same for bi-predicted (BI_PRED) blocks: what av1_inter_prediction does for the luma plane when mv_unit->predDirection == BI_PRED
+ * (Codec/EbInterPrediction.c:1254-1290 and :1346-1385): list 0 through convolve[..][..][1] = av1_jnt_convolve_2d / _x / _y / _2d_copy
+ * (C bodies :290-528) into the 16-bit buffer with get_conv_params_no_round(.., do_average = 0, is_compound = 1) (round_0 = 3,
+ * round_1 = COMPOUND_ROUND1_BITS = 7), then list 1 with do_average = 1 averaged into the 8-bit destination (use_jnt_comp_avg = 0,
+ * round_bits = 4).  One interp_filters pair serves both lists, as in the reference's call.  Block i reads around
+ * d_src0 + src0_offset with (subpel_x0, subpel_y0) and around d_src1 + src1_offset with (subpel_x1, subpel_y1) under the window
+ * rules of the single-reference entry, and writes width x height samples at d_dst + dst_offset. */
+typedef struct svthip_convolve_compound_desc {
+    uint32_t src0_offset;
+    uint32_t src1_offset;
+    uint32_t dst_offset;
+    uint8_t subpel0; /* subpel_x0 | subpel_y0 << 4 */
+    uint8_t subpel1; /* subpel_x1 | subpel_y1 << 4 */
+    uint8_t filter_x, filter_y;
+} svthip_convolve_compound_desc;
+
+int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx *ctx, const uint8_t *d_src0, uint32_t src0_stride, const uint8_t *d_src1,
+                                               uint32_t src1_stride, uint8_t *d_dst, uint32_t dst_stride,
+                                               const svthip_convolve_compound_desc *d_desc, uint32_t n_blocks, uint32_t width,
+                                               uint32_t height, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batching layer for the transform / quantisation callers.  The reference calls its T/Q kernels one TU and one
  * transform type at a time from ProductFullLoopTxSearch (Codec/EbFullLoop.c:1138-1352: for every tx_type candidate of a TU:

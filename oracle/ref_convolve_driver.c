@@ -29,3 +29,27 @@ void ref_av1_convolve_sr(const uint8_t *src, int32_t src_stride, uint8_t *dst, i
     else if (subpel_x) av1_convolve_x_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
     else av1_convolve_2d_copy_sr_c(src, src_stride, dst, dst_stride, w, h, &px, &py, subpel_x, subpel_y, &cp);
 }
+
+/* The luma plane of a BI_PRED block (Codec/EbInterPrediction.c:1254-1290 list 0 with do_average = 0, :1346-1385 list 1 with
+ * do_average = 1): both lists through convolve[subpel_x != 0][subpel_y != 0][1] = av1_jnt_convolve_* with
+ * get_conv_params_no_round(.., is_compound = 1, EB_8BIT) (round_1 = COMPOUND_ROUND1_BITS, use_jnt_comp_avg = 0) and the shared
+ * 16-bit tmp_dstY buffer of stride 128; one interp_filters pair for both lists. */
+DECL(av1_jnt_convolve_2d_c) DECL(av1_jnt_convolve_x_c) DECL(av1_jnt_convolve_y_c) DECL(av1_jnt_convolve_2d_copy_c)
+
+void ref_av1_convolve_compound(const uint8_t *src0, int32_t src0_stride, const uint8_t *src1, int32_t src1_stride, uint8_t *dst,
+                               int32_t dst_stride, int32_t w, int32_t h, int filter_x, int filter_y, int subpel_x0, int subpel_y0,
+                               int subpel_x1, int subpel_y1)
+{
+    static uint16_t tmp[128 * 128];
+    InterpFilterParams px = av1_get_interp_filter_params_with_block_size((InterpFilter)filter_x, w);
+    InterpFilterParams py = av1_get_interp_filter_params_with_block_size((InterpFilter)filter_y, h);
+    for (int list = 0; list < 2; list++) {
+        ConvolveParams cp = get_conv_params_no_round(0, list, 0, tmp, 128, 1, EB_8BIT);
+        const uint8_t *src = list ? src1 : src0;
+        const int32_t st = list ? src1_stride : src0_stride, sx = list ? subpel_x1 : subpel_x0, sy = list ? subpel_y1 : subpel_y0;
+        if (sx && sy) av1_jnt_convolve_2d_c(src, st, dst, dst_stride, w, h, &px, &py, sx, sy, &cp);
+        else if (sy) av1_jnt_convolve_y_c(src, st, dst, dst_stride, w, h, &px, &py, sx, sy, &cp);
+        else if (sx) av1_jnt_convolve_x_c(src, st, dst, dst_stride, w, h, &px, &py, sx, sy, &cp);
+        else av1_jnt_convolve_2d_copy_c(src, st, dst, dst_stride, w, h, &px, &py, sx, sy, &cp);
+    }
+}

@@ -11,6 +11,7 @@
  *   dispatch convolve[subpel_x != 0][subpel_y != 0][0]       :898-911, call site :1276-1287
  *   filter choice av1_get_interp_filter_params_with_block_size :985-995 (4-tap kernels for blocks <= 4 wide / high)
  *   conv params get_conv_params_no_round(.., is_compound = 0, bd = 8): round_0 = 3, round_1 = 11 (convolve.h:115-143)
+ *   av1_jnt_convolve_{2d,x,y,2d_copy}_c  :290-528           the compound (BI_PRED) forms: 16-bit intermediate per list, plain average
  * PINNED against the reference's own functions (oracle/ref_convolve_driver.c) in tests/test_convolve_vs_ref.py for every filter,
  * every phase pair and every AV1 block size.
  */
@@ -69,6 +70,77 @@ void orc_av1_convolve_sr(const uint8_t *src, int32_t src_stride, uint8_t *dst, i
     } else {
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) dst[y * dst_stride + x] = src[y * src_stride + x];
+    }
+}
+
+/* One list of a compound (BI_PRED) block: the 16-bit value av1_jnt_convolve_{2d,x,y,2d_copy}_c store into conv_params->dst
+ * (EbInterPrediction.c:290-528; round_0 = 3, round_1 = COMPOUND_ROUND1_BITS = 7: offset_bits = 19, round_offset = 6144). */
+static void compound_list(const uint8_t *src, int32_t src_stride, uint16_t *res, int32_t w, int32_t h, const int16_t *fx, const int16_t *fy,
+                          int subpel_x, int subpel_y)
+{
+    if (subpel_x && subpel_y) {
+        static int16_t im[(128 + 7) * 128];
+        const uint8_t *s = src - 3 * src_stride;
+        for (int y = 0; y < h + 7; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << 14;
+                for (int k = 0; k < 8; k++) sum += fx[k] * s[y * src_stride + x - 3 + k];
+                im[y * w + x] = (int16_t)((sum + 4) >> 3);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << 19;
+                for (int k = 0; k < 8; k++) sum += fy[k] * im[(y + k) * w + x];
+                res[y * w + x] = (uint16_t)((sum + 64) >> 7);
+            }
+    } else if (subpel_y) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t r = 0;
+                for (int k = 0; k < 8; k++) r += fy[k] * src[(y - 3 + k) * src_stride + x];
+                r *= 16; /* 1 << (FILTER_BITS - round_0) */
+                res[y * w + x] = (uint16_t)(((r + 64) >> 7) + 6144);
+            }
+    } else if (subpel_x) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t r = 0;
+                for (int k = 0; k < 8; k++) r += fx[k] * src[y * src_stride + x - 3 + k];
+                res[y * w + x] = (uint16_t)(((r + 4) >> 3) + 6144); /* bits = FILTER_BITS - round_1 = 0 */
+            }
+    } else {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) res[y * w + x] = (uint16_t)((src[y * src_stride + x] << 4) + 6144);
+    }
+}
+
+/* BI_PRED luma of av1_inter_prediction (:1254-1290 + :1346-1385): list 0 into the 16-bit buffer, list 1 averaged with it
+ * (use_jnt_comp_avg = 0), round_bits = 4. */
+void orc_av1_convolve_compound(const uint8_t *src0, int32_t src0_stride, const uint8_t *src1, int32_t src1_stride, uint8_t *dst,
+                               int32_t dst_stride, int32_t w, int32_t h, int filter_x, int filter_y, int subpel_x0, int subpel_y0,
+                               int subpel_x1, int subpel_y1)
+{
+    static uint16_t r0[128 * 128], r1[128 * 128];
+    const int fxi = filter_index(filter_x, w), fyi = filter_index(filter_y, h);
+    compound_list(src0, src0_stride, r0, w, h, kFilters[fxi][subpel_x0 & 15], kFilters[fyi][subpel_y0 & 15], subpel_x0, subpel_y0);
+    compound_list(src1, src1_stride, r1, w, h, kFilters[fxi][subpel_x1 & 15], kFilters[fyi][subpel_y1 & 15], subpel_x1, subpel_y1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int32_t tmp = ((int32_t)r0[y * w + x] + (int32_t)r1[y * w + x]) >> 1;
+            tmp -= 6144;
+            dst[y * dst_stride + x] = clip8((tmp + 8) >> 4);
+        }
+}
+
+/* batch form of the device entry: desc = { src0_offset, src1_offset, dst_offset,
+ * subpel_x0 | subpel_y0 << 4 | subpel_x1 << 8 | subpel_y1 << 12 | filter_x << 16 | filter_y << 24 } */
+void orc_av1_convolve_compound_batch(const uint8_t *src0, int32_t src0_stride, const uint8_t *src1, int32_t src1_stride, uint8_t *dst,
+                                     int32_t dst_stride, const uint32_t *desc, uint32_t n, int32_t w, int32_t h)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *d = desc + 4 * i, p = d[3];
+        orc_av1_convolve_compound(src0 + d[0], src0_stride, src1 + d[1], src1_stride, dst + d[2], dst_stride, w, h, (p >> 16) & 255, (p >> 24) & 255,
+                                  p & 15, (p >> 4) & 15, (p >> 8) & 15, (p >> 12) & 15);
     }
 }
 

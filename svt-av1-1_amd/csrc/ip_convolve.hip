@@ -39,10 +39,12 @@ __device__ __forceinline__ int filter_index(int f, int size)
     return f;
 }
 
-template <int RB>
-__global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, uint8_t* __restrict__ dst,
-                                                              uint32_t dst_stride, const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h,
-                                                              int blocks_per_wg)
+// COMPOUND: descriptors are svthip_convolve_compound_desc; both lists are run (list 0's 16-bit results parked in LDS) and averaged like
+// av1_inter_prediction's BI_PRED path: av1_jnt_convolve_* with round_1 = 7, round_offset = 6144, round_bits = 4 (EbInterPrediction.c:290-528).
+template <int RB, bool COMPOUND>
+__global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __restrict__ src0, uint32_t src0_stride, const uint8_t* __restrict__ src1,
+                                                              uint32_t src1_stride, uint8_t* __restrict__ dst, uint32_t dst_stride,
+                                                              const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h, int blocks_per_wg)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     lds_u8* im = (lds_u8*)smem;  // int16 [blocks_per_wg][h + 7][w]
@@ -50,95 +52,130 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
     const uint32_t b0 = blockIdx.x * (uint32_t)blocks_per_wg;
     const int nb = (int)min((uint32_t)blocks_per_wg, n_blocks - b0);
     const int rows_im = h + 7, w4 = w >> 2, blk_bytes = rows_im * w * 2;
+    lds_u8* res0 = im + blocks_per_wg * blk_bytes;  // COMPOUND: uint16 [blocks_per_wg][h][w], list 0's results
 
-    // ---- pass 1: intermediate rows ----
-    const int items1 = nb * rows_im * w4;
-    for (int i = tid; i < items1; i += 256) {
-        const int g = i / (rows_im * w4), rem = i - g * (rows_im * w4), r = rem / w4, c = 4 * (rem - r * w4);
-        const uint4 d = desc[b0 + g];
-        const int sx = d.z & 15, sy = (d.z >> 8) & 15;
-        const int rows = sy ? rows_im : h;  // a vertical filter needs 3 rows above and 4 below
-        if (r >= rows) continue;
-        const uint8_t* p = src + d.x + (int64_t)(r - (sy ? 3 : 0)) * src_stride + c - (sx ? 3 : 0);
-        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-        const uint32_t sh = (uint32_t)(a & 3u);
-        uint32_t o01, o23;  // four int16
-        if (sx) {
-            const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            const uint32_t e0 = __builtin_amdgcn_alignbyte(q1, q0, sh) ^ 0x80808080u, e1 = __builtin_amdgcn_alignbyte(q2, q1, sh) ^ 0x80808080u,
-                           e2 = __builtin_amdgcn_alignbyte(q3, q2, sh) ^ 0x80808080u;  // bytes p[0..11] - 128
-            const int fi = filter_index((d.z >> 16) & 255, w);
-            const uint32_t flo = kInterp[fi][sx][0], fhi = kInterp[fi][sx][1];
-            // reference: sum = (1 << 14) + sum f p (2-D) or sum f p (x only); sum f p = sum f (p - 128) + 128 * 128; then (sum + 4) >> 3
-            const int bias = (sy ? (1 << 15) : (1 << 14)) + 4;
-            int v[4];
+#pragma unroll 1
+    for (int list = 0; list < (COMPOUND ? 2 : 1); list++) {
+        const uint8_t* src = list ? src1 : src0;
+        const uint32_t src_stride = list ? src1_stride : src0_stride;
+        // ---- pass 1: intermediate rows ----
+        const int items1 = nb * rows_im * w4;
+        for (int i = tid; i < items1; i += 256) {
+            const int g = i / (rows_im * w4), rem = i - g * (rows_im * w4), r = rem / w4, c = 4 * (rem - r * w4);
+            const uint4 d = desc[b0 + g];
+            const uint32_t soff = COMPOUND ? (list ? d.y : d.x) : d.x;
+            const int sx = COMPOUND ? (int)((d.w >> (8 * list)) & 15) : (int)(d.z & 15);
+            const int sy = COMPOUND ? (int)((d.w >> (8 * list + 4)) & 15) : (int)((d.z >> 8) & 15);
+            const int fxt = COMPOUND ? (int)((d.w >> 16) & 255) : (int)((d.z >> 16) & 255);
+            const int rows = sy ? rows_im : h;  // a vertical filter needs 3 rows above and 4 below
+            if (r >= rows) continue;
+            const uint8_t* p = src + soff + (int64_t)(r - (sy ? 3 : 0)) * src_stride + c - (sx ? 3 : 0);
+            const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3u);
+            uint32_t o01, o23;  // four int16
+            if (sx) {
+                const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(q1, q0, sh) ^ 0x80808080u, e1 = __builtin_amdgcn_alignbyte(q2, q1, sh) ^ 0x80808080u,
+                               e2 = __builtin_amdgcn_alignbyte(q3, q2, sh) ^ 0x80808080u;  // bytes p[0..11] - 128
+                const int fi = filter_index(fxt, w);
+                const uint32_t flo = kInterp[fi][sx][0], fhi = kInterp[fi][sx][1];
+                // reference: sum = (1 << 14) + sum f p (2-D) or sum f p (x only); sum f p = sum f (p - 128) + 128 * 128; then (sum + 4) >> 3
+                const int bias = (sy ? (1 << 15) : (1 << 14)) + 4;
+                int v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t lo = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0, hi = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;
-                v[k] = __builtin_amdgcn_sdot4((int)hi, (int)fhi, __builtin_amdgcn_sdot4((int)lo, (int)flo, bias, false), false) >> 3;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t lo = k ? __builtin_amdgcn_alignbyte(e1, e0, k) : e0, hi = k ? __builtin_amdgcn_alignbyte(e2, e1, k) : e1;
+                    v[k] = __builtin_amdgcn_sdot4((int)hi, (int)fhi, __builtin_amdgcn_sdot4((int)lo, (int)flo, bias, false), false) >> 3;
+                }
+                o01 = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+                o23 = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+            } else {  // no horizontal filter: the pixels themselves
+                const uint32_t e0 = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+                o01 = (e0 & 0xffu) | ((e0 & 0xff00u) << 8);
+                o23 = ((e0 >> 16) & 0xffu) | ((e0 >> 8) & 0xff0000u);
             }
-            o01 = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
-            o23 = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
-        } else {  // no horizontal filter: the pixels themselves
-            const uint32_t e0 = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
-            o01 = (e0 & 0xffu) | ((e0 & 0xff00u) << 8);
-            o23 = ((e0 >> 16) & 0xffu) | ((e0 >> 8) & 0xff0000u);
+            lds_u32* o = reinterpret_cast<lds_u32*>(im + g * blk_bytes + (r * w + c) * 2);
+            o[0] = o01;
+            o[1] = o23;
         }
-        lds_u32* o = reinterpret_cast<lds_u32*>(im + g * blk_bytes + (r * w + c) * 2);
-        o[0] = o01;
-        o[1] = o23;
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- pass 2: columns ----
-    const int w2 = w >> 1, bands = (h + RB - 1) / RB;
-    const int items2 = nb * bands * w2;
-    for (int i = tid; i < items2; i += 256) {
-        const int g = i / (bands * w2), rem = i - g * (bands * w2), band = rem / w2, cp = rem - band * w2;
-        const uint4 d = desc[b0 + g];
-        const int sx = d.z & 15, sy = (d.z >> 8) & 15;
-        int f[8], c0, shift, sub;
-        if (sy) {
-            const int fi = filter_index((d.z >> 24) & 255, h);
-            const uint32_t flo = kInterp[fi][sy][0], fhi = kInterp[fi][sy][1];
+        // ---- pass 2: columns ----
+        const int w2 = w >> 1, bands = (h + RB - 1) / RB;
+        const int items2 = nb * bands * w2;
+        for (int i = tid; i < items2; i += 256) {
+            const int g = i / (bands * w2), rem = i - g * (bands * w2), band = rem / w2, cp = rem - band * w2;
+            const uint4 d = desc[b0 + g];
+            const int sx = COMPOUND ? (int)((d.w >> (8 * list)) & 15) : (int)(d.z & 15);
+            const int sy = COMPOUND ? (int)((d.w >> (8 * list + 4)) & 15) : (int)((d.z >> 8) & 15);
+            const int fyt = COMPOUND ? (int)((d.w >> 24) & 255) : (int)((d.z >> 24) & 255);
+            const uint32_t doff = COMPOUND ? d.z : d.y;
+            int f[8], c0, shift, sub;
+            if (sy) {
+                const int fi = filter_index(fyt, h);
+                const uint32_t flo = kInterp[fi][sy][0], fhi = kInterp[fi][sy][1];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                f[k] = (int)(int8_t)(flo >> (8 * k));
-                f[4 + k] = (int)(int8_t)(fhi >> (8 * k));
+                for (int k = 0; k < 4; k++) {
+                    f[k] = (int)(int8_t)(flo >> (8 * k));
+                    f[4 + k] = (int)(int8_t)(fhi >> (8 * k));
+                }
+                if (!COMPOUND) {
+                    if (sx) { c0 = (1 << 19) + (1 << 10); shift = 11; sub = (1 << 8) + (1 << 7); }  // 2-D: offset_bits = 19, round_1 = 11
+                    else { c0 = 64; shift = 7; sub = 0; }                                          // y only: ROUND_POWER_OF_TWO(res, FILTER_BITS)
+                } else {
+                    if (sx) { c0 = (1 << 19) + 64; shift = 7; sub = 0; }  // ROUND(sum, round_1 = 7)
+                    else { c0 = 4; shift = 3; sub = -6144; }               // ROUND(res << 4, 7) + round_offset
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) f[k] = k == 0;
+                if (!COMPOUND) {
+                    if (sx) { c0 = 8; shift = 4; }  // x only: second rounding, bits = FILTER_BITS - round_0
+                    else { c0 = 0; shift = 0; }     // copy
+                } else {
+                    if (!sx) f[0] = 16;             // copy: (p << 4) + round_offset;  x only: ROUND(sum, 3) + round_offset
+                    c0 = 6144; shift = 0;
+                }
+                sub = 0;
             }
-            if (sx) { c0 = (1 << 19) + (1 << 10); shift = 11; sub = (1 << 8) + (1 << 7); }  // 2-D: offset_bits = 19, round_1 = 11
-            else { c0 = 64; shift = 7; sub = 0; }                                          // y only: ROUND_POWER_OF_TWO(res, FILTER_BITS)
-        } else {
+            const lds_u32* col = reinterpret_cast<const lds_u32*>(im + g * blk_bytes) + cp;  // dword = 2 int16 columns; row pitch w2 dwords
+            const int y0 = band * RB;
+            int lo[RB + 7], hi[RB + 7];
 #pragma unroll
-            for (int k = 0; k < 8; k++) f[k] = k == 0;
-            if (sx) { c0 = 8; shift = 4; }  // x only: second rounding, bits = FILTER_BITS - round_0
-            else { c0 = 0; shift = 0; }     // copy
-            sub = 0;
-        }
-        const lds_u32* col = reinterpret_cast<const lds_u32*>(im + g * blk_bytes) + cp;  // dword = 2 int16 columns; row pitch w2 dwords
-        const int y0 = band * RB;
-        int lo[RB + 7], hi[RB + 7];
-#pragma unroll
-        for (int j = 0; j < RB + 7; j++) {
-            const uint32_t v = (y0 + j < rows_im) ? col[(y0 + j) * w2] : 0u;
-            lo[j] = (int)(int16_t)(v & 0xffffu);
-            hi[j] = (int)v >> 16;
-        }
-        uint8_t* out = dst + d.y + (size_t)y0 * dst_stride + 2 * cp;
-#pragma unroll
-        for (int j = 0; j < RB; j++) {
-            if (y0 + j >= h) break;
-            int a0 = c0, a1 = c0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                a0 += __mul24(f[k], lo[j + k]);  // |tap| <= 128, |sample| < 2^15: v_mad_i32_i24
-                a1 += __mul24(f[k], hi[j + k]);
+            for (int j = 0; j < RB + 7; j++) {
+                const uint32_t v = (y0 + j < rows_im) ? col[(y0 + j) * w2] : 0u;
+                lo[j] = (int)(int16_t)(v & 0xffffu);
+                hi[j] = (int)v >> 16;
             }
-            const int r0 = min(max((a0 >> shift) - sub, 0), 255), r1 = min(max((a1 >> shift) - sub, 0), 255);
-            out[(size_t)j * dst_stride] = (uint8_t)r0;
-            out[(size_t)j * dst_stride + 1] = (uint8_t)r1;
+            uint8_t* out = dst + doff + (size_t)y0 * dst_stride + 2 * cp;
+            lds_u32* park = reinterpret_cast<lds_u32*>(res0 + g * h * w * 2) + cp;  // dword = 2 uint16 columns; row pitch w2 dwords
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                if (y0 + j >= h) break;
+                int a0 = c0, a1 = c0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    a0 += __mul24(f[k], lo[j + k]);  // |tap| <= 128, |sample| < 2^15: v_mad_i32_i24
+                    a1 += __mul24(f[k], hi[j + k]);
+                }
+                int r0 = (a0 >> shift) - sub, r1 = (a1 >> shift) - sub;
+                if (COMPOUND) {
+                    if (list == 0) {
+                        park[(y0 + j) * w2] = ((uint32_t)r0 & 0xffffu) | ((uint32_t)r1 << 16);
+                        continue;
+                    }
+                    const uint32_t pv = park[(y0 + j) * w2];
+                    r0 = ((((int)(pv & 0xffffu) + (r0 & 0xffff)) >> 1) - 6144 + 8) >> 4;  // CONV_BUF_TYPE is uint16_t
+                    r1 = ((((int)(pv >> 16) + (r1 & 0xffff)) >> 1) - 6144 + 8) >> 4;
+                }
+                r0 = min(max(r0, 0), 255);
+                r1 = min(max(r1, 0), 255);
+                out[(size_t)j * dst_stride] = (uint8_t)r0;
+                out[(size_t)j * dst_stride + 1] = (uint8_t)r1;
+            }
         }
+        if (COMPOUND) __syncthreads();  // list 1's pass 1 overwrites the intermediate rows
     }
 }
 
@@ -159,10 +196,37 @@ hipError_t launch_av1_convolve_sr(const uint8_t* src, uint32_t src_stride, uint8
     const size_t lds = (size_t)per * (h + 7) * w * 2;
     const uint32_t grid = (n_blocks + per - 1) / per;
     if (h >= 8)
-        hipLaunchKernelGGL(av1_convolve_sr_kernel<8>, dim3(grid), dim3(256), lds, s, src, src_stride, dst, dst_stride,
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<8, false>), dim3(grid), dim3(256), lds, s, src, src_stride, src, src_stride, dst, dst_stride,
                            reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
     else
-        hipLaunchKernelGGL(av1_convolve_sr_kernel<4>, dim3(grid), dim3(256), lds, s, src, src_stride, dst, dst_stride,
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<4, false>), dim3(grid), dim3(256), lds, s, src, src_stride, src, src_stride, dst, dst_stride,
+                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
+    return hipGetLastError();
+}
+
+size_t convolve_compound_lds_bytes(int w, int h)
+{
+    const int per = w * h >= 4096 ? 1 : 4096 / (w * h);
+    return (size_t)per * ((h + 7) * w * 2 + h * w * 2);
+}
+
+// the two instantiations whose dynamic LDS can pass 64 KB (128-wide blocks): svthip_abi.hip raises their limit once per device
+const void* convolve_compound_kernel_ptr(int rb)
+{
+    return rb == 8 ? reinterpret_cast<const void*>(&av1_convolve_sr_kernel<8, true>) : reinterpret_cast<const void*>(&av1_convolve_sr_kernel<4, true>);
+}
+
+hipError_t launch_av1_convolve_compound(const uint8_t* src0, uint32_t src0_stride, const uint8_t* src1, uint32_t src1_stride, uint8_t* dst,
+                                        uint32_t dst_stride, const svthip_convolve_compound_desc* desc, uint32_t n_blocks, int w, int h, hipStream_t s)
+{
+    const int per = w * h >= 4096 ? 1 : 4096 / (w * h);
+    const size_t lds = convolve_compound_lds_bytes(w, h);
+    const uint32_t grid = (n_blocks + per - 1) / per;
+    if (h >= 8)
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<8, true>), dim3(grid), dim3(256), lds, s, src0, src0_stride, src1, src1_stride, dst, dst_stride,
+                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
+    else
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<4, true>), dim3(grid), dim3(256), lds, s, src0, src0_stride, src1, src1_stride, dst, dst_stride,
                            reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
     return hipGetLastError();
 }

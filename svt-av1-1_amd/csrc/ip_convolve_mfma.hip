@@ -52,29 +52,30 @@ __device__ __forceinline__ uint32_t seq4(uint64_t T, int s)
 
 }  // namespace
 
-// TY = output tiles stacked vertically per wave: they share the IM tile between them (TY + 1 IM tiles instead of 2 TY) and the tap fragments
+// Both passes of ONE reference list for the wave's TY stacked output tiles: res[ot][reg] = (sum_k g[k] IM[..] + C2) >> S2 in the accumulator
+// layout (column n on the lane, row (reg & 3) + 8 (reg >> 2) + 4 hh in the registers).  `compound` selects the constants of the
+// av1_jnt_convolve_* forms (16-bit intermediate of one list, EbInterPrediction.c:290-528) instead of the single-reference ones.
 template <int TY>
-__global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, uint8_t* __restrict__ dst,
-                                                                   uint32_t dst_stride, const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h)
+__device__ __forceinline__ void conv_list_tiles(const uint8_t* __restrict__ src, uint32_t src_stride, uint32_t src_off, int sx, int sy, int fx, int fy,
+                                                bool compound, int tx, int ty, int n, int hh, v16i (&res)[TY])
 {
-    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
-    const int tiles_x = w >> 5, tiles = tiles_x * (h / (32 * TY));
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const uint32_t b = wave / (uint32_t)tiles;
-    if (b >= n_blocks) return;
-    const int t = (int)(wave - b * (uint32_t)tiles), ty = t / tiles_x, tx = t - ty * tiles_x;
-    const uint4 d = desc[b];
-    const int sx = d.z & 15, sy = (d.z >> 8) & 15;
-    // taps as 8 packed signed bytes; a missing pass is the unit tap at k = 0 on an unshifted window
-    uint64_t F = 1, G = 1;
-    if (sx) F = ((uint64_t)kInterpM[(d.z >> 16) & 255][sx][1] << 32) | kInterpM[(d.z >> 16) & 255][sx][0];
-    if (sy) G = ((uint64_t)kInterpM[(d.z >> 24) & 255][sy][1] << 32) | kInterpM[(d.z >> 24) & 255][sy][0];
+    // taps as 8 packed signed bytes; a missing pass is the unit tap at k = 0 on an unshifted window (16 for the compound copy: p << 4)
+    uint64_t F = 1, G = (compound && !sx && !sy) ? 16 : 1;
+    if (sx) F = ((uint64_t)kInterpM[fx][sx][1] << 32) | kInterpM[fx][sx][0];
+    if (sy) G = ((uint64_t)kInterpM[fy][sy][1] << 32) | kInterpM[fy][sy][0];
     const int c0 = sx ? -3 : 0, r0 = sy ? -3 : 0;
     const int rows_needed = 32 * TY + (sy ? 7 : 0), n_kx = sx ? 2 : 1, n_im = TY + (sy ? 1 : 0), n_e = sy ? 2 : 1;
     const int C1 = sx ? 32768 + 4 : 128, S1 = sx ? 3 : 0;
-    const int C2 = sx ? (sy ? -261120 : -2040) : (sy ? 64 : 0), S2 = sx ? (sy ? 11 : 4) : (sy ? 7 : 0);
-    // 32-bit offsets from the (uniform) plane pointers: one VALU add per access instead of 64-bit pointer arithmetic
-    const uint32_t base = d.x + (uint32_t)((32 * TY * ty + r0) * (int)src_stride + 32 * tx + c0);
+    int C2, S2;
+    if (!compound) {
+        C2 = sx ? (sy ? -261120 : -2040) : (sy ? 64 : 0);
+        S2 = sx ? (sy ? 11 : 4) : (sy ? 7 : 0);
+    } else {  // round_1 = 7, offset_bits = 19, round_offset = 6144; IM of the x-only case carries + 2048 here
+        C2 = sx ? (sy ? (1 << 19) + 64 : 4096) : (sy ? 4 + 8 * 6144 : 6144);
+        S2 = sx ? (sy ? 7 : 0) : (sy ? 3 : 0);
+    }
+    // 32-bit offsets from the (uniform) plane pointer: one VALU add per access instead of 64-bit pointer arithmetic
+    const uint32_t base = src_off + (uint32_t)((32 * TY * ty + r0) * (int)src_stride + 32 * tx + c0);
 
     // Tx fragments: element j of lane half hh is k = 16 hh + j of column chunk c; coefficient f[k + 32 c - n]
     v4i bx[2];
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
 #pragma unroll
         for (int q = 0; q < 4; q++) ay[e][q] = (int)seq4(G, 32 * e + 8 * q + 4 * hh - n);
 
-    // all sample fragments are requested up front (one memory latency per wave), then the IM tiles are worked through one at a time
+    // all sample fragments are requested up front (one memory latency per wave and list), then the IM tiles are worked through one at a time
     v4i a_frag[TY + 1][2];
 #pragma unroll
     for (int it = 0; it < TY + 1; it++)
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
         if (it < n_im) {
             v16i acc;
 #pragma unroll
-            for (int i = 0; i < 16; i++) acc[i] = sx ? 0 : C1;  // with a horizontal filter the bias rides in four spare k slots (below)
+            for (int i = 0; i < 16; i++) acc[i] = sx ? 0 : C1;  // with a horizontal filter the bias rides in four spare k slots (above)
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 if (c < n_kx) {
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
     // writes two whole 32-byte row segments (the transposed form, four pixels per lane, scatters 4-byte pieces over 32 rows and measured slower)
 #pragma unroll
     for (int ot = 0; ot < TY; ot++) {
-        __builtin_amdgcn_sched_barrier(0);  // one output tile's accumulators at a time (the scheduler interleaves them: 64 AGPRs, 3 waves / SIMD)
+        __builtin_amdgcn_sched_barrier(0);  // one output tile's accumulators at a time
         v16i olo, ohi;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -157,13 +158,57 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_mfma_kernel(const uint8_t
                 ohi = __builtin_amdgcn_mfma_i32_32x32x32_i8(ay[e], im_hi[ot + e], ohi, 0, 0, 0);
             }
         }
-        const uint32_t o = d.y + (uint32_t)(32 * (TY * ty + ot) + 4 * hh) * dst_stride + (uint32_t)(32 * tx + n);
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             int v = ((ohi[reg] << 7) + olo[reg]) >> S2;
             // shift-then-clip of two neighbours can be fused into v_ashr_pk_u8_i32, whose result did not match the C semantics (gfx950, ROCm 7.2;
             // same finding as me_subpel_common.h::hfilt1): keep the shifted value opaque
             asm volatile("" : "+v"(v));
+            res[ot][reg] = v;
+        }
+    }
+}
+
+// TY = output tiles stacked vertically per wave: they share the IM tile between them (TY + 1 IM tiles instead of 2 TY) and the tap fragments.
+// COMPOUND: descriptors are svthip_convolve_compound_desc, both lists are run and averaged like av1_inter_prediction's BI_PRED path.
+template <int TY, bool COMPOUND>
+__global__ void __launch_bounds__(256) av1_convolve_mfma_kernel(const uint8_t* __restrict__ src0, uint32_t src0_stride, const uint8_t* __restrict__ src1,
+                                                                uint32_t src1_stride, uint8_t* __restrict__ dst, uint32_t dst_stride,
+                                                                const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h)
+{
+    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
+    const int tiles_x = w >> 5, tiles = tiles_x * (h / (32 * TY));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t b = wave / (uint32_t)tiles;
+    if (b >= n_blocks) return;
+    const int t = (int)(wave - b * (uint32_t)tiles), ty = t / tiles_x, tx = t - ty * tiles_x;
+    const uint4 d = desc[b];
+    v16i res[TY];
+    uint32_t dst_off;
+    if (!COMPOUND) {
+        conv_list_tiles<TY>(src0, src0_stride, d.x, d.z & 15, (d.z >> 8) & 15, (d.z >> 16) & 255, (d.z >> 24) & 255, false, tx, ty, n, hh, res);
+        dst_off = d.y;
+    } else {
+        v16i r1[TY];
+        conv_list_tiles<TY>(src0, src0_stride, d.x, d.w & 15, (d.w >> 4) & 15, (d.w >> 16) & 255, (d.w >> 24) & 255, true, tx, ty, n, hh, res);
+        __builtin_amdgcn_sched_barrier(0);
+        conv_list_tiles<TY>(src1, src1_stride, d.y, (d.w >> 8) & 15, (d.w >> 12) & 15, (d.w >> 16) & 255, (d.w >> 24) & 255, true, tx, ty, n, hh, r1);
+#pragma unroll
+        for (int ot = 0; ot < TY; ot++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                int v = ((((res[ot][reg] & 0xffff) + (r1[ot][reg] & 0xffff)) >> 1) - 6144 + 8) >> 4;  // CONV_BUF_TYPE is uint16_t
+                asm volatile("" : "+v"(v));
+                res[ot][reg] = v;
+            }
+        dst_off = d.z;
+    }
+#pragma unroll
+    for (int ot = 0; ot < TY; ot++) {
+        const uint32_t o = dst_off + (uint32_t)(32 * (TY * ty + ot) + 4 * hh) * dst_stride + (uint32_t)(32 * tx + n);
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            int v = res[ot][reg];
             v = v < 0 ? 0 : v > 255 ? 255 : v;
             dst[o + (uint32_t)((reg & 3) + 8 * (reg >> 2)) * dst_stride] = (uint8_t)v;
         }
@@ -178,12 +223,25 @@ hipError_t launch_av1_convolve_sr_mfma(const uint8_t* src, uint32_t src_stride, 
     const int ty = (h & 63) == 0 ? 2 : 1;
     const uint64_t waves = (uint64_t)n_blocks * (uint32_t)((w >> 5) * (h / (32 * ty)));
     const dim3 grid((uint32_t)((waves + 3) / 4)), block(256);
+    const uint4* dd = reinterpret_cast<const uint4*>(desc);
     if (ty == 2)
-        hipLaunchKernelGGL(av1_convolve_sr_mfma_kernel<2>, grid, block, 0, s, src, src_stride, dst, dst_stride, reinterpret_cast<const uint4*>(desc),
-                           n_blocks, w, h);
+        hipLaunchKernelGGL((av1_convolve_mfma_kernel<2, false>), grid, block, 0, s, src, src_stride, src, src_stride, dst, dst_stride, dd, n_blocks, w, h);
     else
-        hipLaunchKernelGGL(av1_convolve_sr_mfma_kernel<1>, grid, block, 0, s, src, src_stride, dst, dst_stride, reinterpret_cast<const uint4*>(desc),
-                           n_blocks, w, h);
+        hipLaunchKernelGGL((av1_convolve_mfma_kernel<1, false>), grid, block, 0, s, src, src_stride, src, src_stride, dst, dst_stride, dd, n_blocks, w, h);
+    return hipGetLastError();
+}
+
+hipError_t launch_av1_convolve_compound_mfma(const uint8_t* src0, uint32_t src0_stride, const uint8_t* src1, uint32_t src1_stride, uint8_t* dst,
+                                             uint32_t dst_stride, const svthip_convolve_compound_desc* desc, uint32_t n_blocks, int w, int h, hipStream_t s)
+{
+    const int ty = (h & 63) == 0 ? 2 : 1;
+    const uint64_t waves = (uint64_t)n_blocks * (uint32_t)((w >> 5) * (h / (32 * ty)));
+    const dim3 grid((uint32_t)((waves + 3) / 4)), block(256);
+    const uint4* dd = reinterpret_cast<const uint4*>(desc);
+    if (ty == 2)
+        hipLaunchKernelGGL((av1_convolve_mfma_kernel<2, true>), grid, block, 0, s, src0, src0_stride, src1, src1_stride, dst, dst_stride, dd, n_blocks, w, h);
+    else
+        hipLaunchKernelGGL((av1_convolve_mfma_kernel<1, true>), grid, block, 0, s, src0, src0_stride, src1, src1_stride, dst, dst_stride, dd, n_blocks, w, h);
     return hipGetLastError();
 }
 

@@ -57,7 +57,8 @@ void set_kernel_attrs(int device)
     const void* kernels[] = {reinterpret_cast<const void*>(svthip::fullpel85_kernel),  reinterpret_cast<const void*>(svthip::fullpel209_kernel),
                              reinterpret_cast<const void*>(svthip::subpel85_kernel),   reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
                              reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
-                             reinterpret_cast<const void*>(svthip::subpel_planes_kernel)};
+                             reinterpret_cast<const void*>(svthip::subpel_planes_kernel), svthip::convolve_compound_kernel_ptr(8),
+                             svthip::convolve_compound_kernel_ptr(4)};
     hipError_t st = hipSuccess;
     for (const void* k : kernels) {
         hipFuncAttributes fa;
@@ -755,6 +756,25 @@ int32_t svthip_me_results_to_ref_layout_dev(svthip_ctx* ctx, const svthip_me_cu_
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     hipLaunchKernelGGL(svthip::me_results_ref_layout_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_in, n, d_out);
     HIP_TRY(hipGetLastError());
+    return SVTHIP_OK;
+}
+
+int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx* ctx, const uint8_t* d_src0, uint32_t src0_stride, const uint8_t* d_src1, uint32_t src1_stride,
+                                               uint8_t* d_dst, uint32_t dst_stride, const svthip_convolve_compound_desc* d_desc, uint32_t n_blocks,
+                                               uint32_t width, uint32_t height, void* stream)
+{
+    ENTER(ctx);
+    if (!svthip::convolve_size_valid((int)width, (int)height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "not an AV1 block size%s (width %d)", "", (int)width);
+    if (n_blocks == 0) return SVTHIP_OK;
+    if (!d_src0 || !d_src1 || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !getenv("SVTHIP_CONVOLVE_VALU")) {
+        HIP_TRY(svthip::launch_av1_convolve_compound_mfma(d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width,
+                                                          (int)height, s));
+        return SVTHIP_OK;
+    }
+    HIP_TRY(svthip::launch_av1_convolve_compound(d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
     return SVTHIP_OK;
 }
 

@@ -122,6 +122,9 @@ def lib() -> C.CDLL:
     L.svthip_av1_convolve_sr_batch_dev.restype = C.c_int32
     L.svthip_av1_convolve_sr_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                                    C.c_uint32, C.c_void_p]
+    L.svthip_av1_convolve_compound_batch_dev.restype = C.c_int32
+    L.svthip_av1_convolve_compound_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                         C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.svthip_sad_loop_batch_dev.restype = C.c_int32
     L.svthip_sad_loop_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -420,6 +423,20 @@ class TuBatcher:
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         _check(lib().svthip_tu_batcher_pools(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+
+CONVOLVE_COMPOUND_DESC_DTYPE = np.dtype([("src0_offset", "<u4"), ("src1_offset", "<u4"), ("dst_offset", "<u4"), ("subpel0", "u1"), ("subpel1", "u1"),
+                                         ("filter_x", "u1"), ("filter_y", "u1")])
+assert CONVOLVE_COMPOUND_DESC_DTYPE.itemsize == 16
+
+
+def _av1_convolve_compound_batch_dev(self, d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, width, height, stream=None):
+    """BI_PRED luma prediction of n_blocks blocks of one size (CONVOLVE_COMPOUND_DESC_DTYPE descriptors; subpel = x | y << 4)."""
+    _check(lib().svthip_av1_convolve_compound_batch_dev(self._h, d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, width,
+                                                        height, stream))
+
+
+Context.av1_convolve_compound_batch_dev = _av1_convolve_compound_batch_dev
 
 
 def _sad_loop_batch_dev(self, d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, width, height, sw, sh, d_best_sad, d_best_xy,

@@ -26,6 +26,9 @@ _Static_assert(sizeof(svthip_me_params) == 52 && offsetof(svthip_me_params, hme_
                    offsetof(svthip_me_params, enable_hme_flag) == 44, "svthip_me_params");
 _Static_assert(sizeof(svthip_host_picture) == 24, "svthip_host_picture");
 _Static_assert(sizeof(svthip_sb_origin) == 4, "svthip_sb_origin");
+_Static_assert(sizeof(svthip_convolve_desc) == 16 && sizeof(svthip_convolve_compound_desc) == 16 &&
+                   offsetof(svthip_convolve_compound_desc, subpel0) == 12 && offsetof(svthip_convolve_compound_desc, filter_y) == 15,
+               "svthip_convolve_desc / svthip_convolve_compound_desc");
 _Static_assert(sizeof(svthip_ois_params) == 8 && offsetof(svthip_ois_params, enc_mode) == 6, "svthip_ois_params");
 _Static_assert(sizeof(svthip_me_cu_result) == 24 && offsetof(svthip_me_cu_result, distortion) == 8 && offsetof(svthip_me_cu_result, direction) == 20 &&
                    offsetof(svthip_me_cu_result, totalMeCandidateIndex) == 23, "svthip_me_cu_result");

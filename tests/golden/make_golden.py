@@ -215,6 +215,24 @@ def convolve_fixture():
                                    int(d[i, 2]), int(d[i, 3]))
         out[f"desc_{w}x{h}"] = d
         out[f"out_{w}x{h}"] = res
+    # BI_PRED blocks (av1_jnt_convolve_* pair as av1_inter_prediction drives them), second list from the same picture mirrored
+    me.ref_av1_convolve_compound.restype = None
+    me.ref_av1_convolve_compound.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int] * 6
+    src1 = np.ascontiguousarray(src[::-1, ::-1])
+    out["src1"] = src1
+    for (w, h) in ((8, 8), (16, 64), (64, 64)):
+        n = 40 if w * h <= 1024 else 10
+        d = np.zeros((n, 10), np.int32)   # x0, y0, x1, y1, sx0, sy0, sx1, sy1, fx, fy
+        res = np.zeros((n, h, w), np.uint8)
+        for i in range(n):
+            d[i] = (rng.integers(8, S - w - 8), rng.integers(8, R - h - 8), rng.integers(8, S - w - 8), rng.integers(8, R - h - 8),
+                    rng.integers(0, 16), rng.integers(0, 16), rng.integers(0, 16), rng.integers(0, 16), rng.integers(0, 4), rng.integers(0, 4))
+        d[:4, 4:8] = [[0, 0, 0, 0], [0, 7, 3, 0], [5, 0, 0, 9], [15, 15, 0, 0]]
+        for i in range(n):
+            me.ref_av1_convolve_compound(src.ctypes.data + int(d[i, 1]) * S + int(d[i, 0]), S, src1.ctypes.data + int(d[i, 3]) * S + int(d[i, 2]), S,
+                                         res[i].ctypes.data, w, w, h, int(d[i, 8]), int(d[i, 9]), int(d[i, 4]), int(d[i, 5]), int(d[i, 6]), int(d[i, 7]))
+        out[f"cdesc_{w}x{h}"] = d
+        out[f"cout_{w}x{h}"] = res
     np.savez_compressed(os.path.join(HERE, "convolve.npz"), **out)
 
 

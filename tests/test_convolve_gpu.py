@@ -125,3 +125,69 @@ def test_convolve_rejects_bad_arguments(hip_ctx):
         hip_ctx.av1_convolve_sr_batch_dev(buf.data_ptr(), 256, buf.data_ptr(), 256, buf.data_ptr(), 1, 4, 32)     # 8:1
     with pytest.raises(svtav1_hip.SvtHipError):
         hip_ctx.av1_convolve_sr_batch_dev(buf.data_ptr(), 256, buf.data_ptr(), 256, buf.data_ptr() + 4, 1, 8, 8)  # misaligned descriptors
+
+
+def _oracle_compound(oracle, s0, S0, s1, S1, dst, D, desc, w, h):
+    f = oracle.lib.orc_av1_convolve_compound_batch
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]
+    d = np.zeros((len(desc), 4), np.uint32)
+    d[:, 0], d[:, 1], d[:, 2] = desc["src0_offset"], desc["src1_offset"], desc["dst_offset"]
+    d[:, 3] = desc["subpel0"].astype(np.uint32) | (desc["subpel1"].astype(np.uint32) << 8) | (desc["filter_x"].astype(np.uint32) << 16) | \
+        (desc["filter_y"].astype(np.uint32) << 24)
+    f(s0.ctypes.data, S0, s1.ctypes.data, S1, dst.ctypes.data, D, d.ctypes.data, len(desc), w, h)
+
+
+def _run_compound(hip_ctx, s0, S0, s1, S1, dst, D, desc, w, h):
+    import torch
+    d0 = torch.from_numpy(np.concatenate([s0.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d1 = torch.from_numpy(np.concatenate([s1.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d_dst = torch.from_numpy(dst.reshape(-1).copy()).to("cuda:0")
+    d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+    hip_ctx.av1_convolve_compound_batch_dev(d0.data_ptr(), S0, d1.data_ptr(), S1, d_dst.data_ptr(), D, d_desc.data_ptr(), len(desc), w, h)
+    hip_ctx.synchronize()
+    return d_dst.cpu().numpy().reshape(dst.shape)
+
+
+@pytest.mark.parametrize("size", svtav1_hip.AV1_BLOCK_SIZES_WH)
+def test_convolve_compound_every_block_size(hip_ctx, oracle, size):
+    """BI_PRED prediction (av1_jnt_convolve_* pair) of every AV1 block size: random phases incl. all copy / x-only / y-only / 2-D
+    combinations of the two lists, two planes with different strides, odd destination stride; both kernels where both exist."""
+    pytest.importorskip("torch")
+    w, h = size
+    rng = np.random.default_rng(w * 263 + h)
+    S0, S1, R = 640, 704, 400
+    s0 = rng.integers(0, 256, (R, S0), dtype=np.uint8)
+    s1 = rng.integers(0, 256, (R, S1), dtype=np.uint8)
+    s0[:40] = (((np.arange(S0)[None, :] // 2 + np.arange(40)[:, None] // 3) & 1) * 255).astype(np.uint8)
+    s1[:60, ::2] = 255; s1[:60, 1::2] = 0
+    cols, rows = 512 // w, 256 // h
+    n = min(cols * rows, 200) - 1
+    slots = rng.permutation(cols * rows)[:n]
+    D = 512 + 1
+    dst = np.full((256, D), 0x55, np.uint8)
+    desc = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+    for i, sl in enumerate(slots):
+        bx, by = (int(sl) % cols) * w, (int(sl) // cols) * h
+        off = []
+        for S in (S0, S1):
+            sx = min(max(40 + bx + int(rng.integers(-20, 21)), 8), S - w - 8); sy = min(max(40 + by + int(rng.integers(-20, 21)), 8), R - h - 8)
+            off.append(sy * S + sx)
+        ph = [int(v) for v in rng.integers(0, 16, 4)]
+        if i < 16:
+            a, b = i & 3, i >> 2
+            ph = [(ph[0] or 5) if a & 1 else 0, (ph[1] or 9) if a & 2 else 0, (ph[2] or 3) if b & 1 else 0, (ph[3] or 12) if b & 2 else 0]
+        desc[i] = (off[0], off[1], by * D + bx, ph[0] | (ph[1] << 4), ph[2] | (ph[3] << 4), int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+    want = dst.copy()
+    _oracle_compound(oracle, s0, S0, s1, S1, want, D, desc, w, h)
+    got = _run_compound(hip_ctx, s0, S0, s1, S1, dst, D, desc, w, h)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, (size, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
+    if w % 32 == 0 and h % 32 == 0:
+        import os
+        os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+        try:
+            got2 = _run_compound(hip_ctx, s0, S0, s1, S1, dst, D, desc, w, h)
+        finally:
+            del os.environ["SVTHIP_CONVOLVE_VALU"]
+        assert np.array_equal(got2, want), size

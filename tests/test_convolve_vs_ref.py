@@ -75,3 +75,37 @@ def test_every_block_size_matches_reference(oracle, ref, size):
             ref.ref_av1_convolve_sr(p, S, a.ctypes.data, w + 5, w, h, fx, fy, sx, sy)
             orc(p, S, b.ctypes.data, w + 5, w, h, fx, fy, sx, sy)
             assert np.array_equal(a, b), (w, h, fx, fy, sx, sy)
+
+
+@pytest.mark.parametrize("size", BLOCK_SIZES)
+def test_compound_matches_reference(oracle, ref, size):
+    """BI_PRED luma: both lists through the reference's av1_jnt_convolve_* exactly as av1_inter_prediction drives them, against the
+    oracle's compound restatement: every combination of copy / x-only / y-only / 2-D between the two lists."""
+    w, h = size
+    ref.ref_av1_convolve_compound.restype = None
+    ref.ref_av1_convolve_compound.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int] * 6
+    orc = oracle.lib.orc_av1_convolve_compound
+    orc.restype = None
+    orc.argtypes = ref.ref_av1_convolve_compound.argtypes
+    rng = np.random.default_rng(w * 17 + h)
+    S0, S1 = w + 24, w + 40
+    for kind in range(2):
+        if kind == 0:
+            s0 = rng.integers(0, 256, (h + 16, S0), dtype=np.uint8); s1 = rng.integers(0, 256, (h + 16, S1), dtype=np.uint8)
+        else:
+            yy, xx = np.mgrid[0:h + 16, 0:S0]
+            s0 = (((xx // 2 + yy // 3) & 1) * 255).astype(np.uint8)
+            s1 = np.full((h + 16, S1), 255, np.uint8); s1[::3] = 0
+        for trial in range(20):
+            fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            ph = [int(v) for v in rng.integers(0, 16, 4)]
+            if trial < 16:   # all 4 x 4 case combinations
+                a, b = trial & 3, trial >> 2
+                ph[0] = ph[0] or 5 if a & 1 else 0; ph[1] = (ph[1] or 9) if a & 2 else 0
+                ph[2] = (ph[2] or 3) if b & 1 else 0; ph[3] = (ph[3] or 12) if b & 2 else 0
+                ph[0] = (ph[0] or 5) if a & 1 else 0
+            x = np.zeros((h, w + 3), np.uint8); y = np.zeros((h, w + 3), np.uint8)
+            args = (s0.ctypes.data + 8 * S0 + 8, S0, s1.ctypes.data + 8 * S1 + 8, S1)
+            ref.ref_av1_convolve_compound(*args, x.ctypes.data, w + 3, w, h, fx, fy, *ph)
+            orc(*args, y.ctypes.data, w + 3, w, h, fx, fy, *ph)
+            assert np.array_equal(x, y), (w, h, fx, fy, ph)

@@ -315,3 +315,50 @@ def test_hip_pa_planes_and_sad_loop_match_golden(hip_ctx):
         want = g[f"sl_{name}_res"]
         assert np.array_equal(d_sad.cpu().numpy().astype(np.int64), want[:, 0]), name
         assert np.array_equal(d_xy.cpu().numpy().reshape(n, 2).astype(np.int64), want[:, 1:3]), name
+
+
+def _compound_cases(g):
+    for key in g.files:
+        if key.startswith("cdesc_"):
+            w, h = (int(v) for v in key[6:].split("x"))
+            yield w, h, g[key], g[f"cout_{w}x{h}"]
+
+
+def test_oracle_convolve_compound_matches_golden(oracle):
+    import ctypes as C
+    g = _load("convolve.npz")
+    s0, s1 = np.ascontiguousarray(g["src"]), np.ascontiguousarray(g["src1"])
+    S = s0.shape[1]
+    f = oracle.lib.orc_av1_convolve_compound
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int] * 6
+    for w, h, d, want in _compound_cases(g):
+        for i in range(len(d)):
+            got = np.zeros((h, w), np.uint8)
+            f(s0.ctypes.data + int(d[i, 1]) * S + int(d[i, 0]), S, s1.ctypes.data + int(d[i, 3]) * S + int(d[i, 2]), S, got.ctypes.data, w, w, h,
+              int(d[i, 8]), int(d[i, 9]), int(d[i, 4]), int(d[i, 5]), int(d[i, 6]), int(d[i, 7]))
+            assert np.array_equal(got, want[i]), (w, h, i)
+
+
+@pytest.mark.gpu
+def test_hip_convolve_compound_matches_golden(hip_ctx):
+    torch = pytest.importorskip("torch")
+    g = _load("convolve.npz")
+    s0, s1 = np.ascontiguousarray(g["src"]), np.ascontiguousarray(g["src1"])
+    S = s0.shape[1]
+    d0 = torch.from_numpy(np.concatenate([s0.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    d1 = torch.from_numpy(np.concatenate([s1.reshape(-1), np.zeros(64, np.uint8)])).to("cuda:0")
+    for w, h, d, want in _compound_cases(g):
+        n = len(d)
+        desc = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+        desc["src0_offset"] = d[:, 1] * S + d[:, 0]
+        desc["src1_offset"] = d[:, 3] * S + d[:, 2]
+        desc["dst_offset"] = np.arange(n) * w * h
+        desc["subpel0"] = d[:, 4] | (d[:, 5] << 4)
+        desc["subpel1"] = d[:, 6] | (d[:, 7] << 4)
+        desc["filter_x"], desc["filter_y"] = d[:, 8], d[:, 9]
+        d_dst = torch.zeros(n * w * h + 64, dtype=torch.uint8, device="cuda:0")
+        d_desc = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        hip_ctx.av1_convolve_compound_batch_dev(d0.data_ptr(), S, d1.data_ptr(), S, d_dst.data_ptr(), w, d_desc.data_ptr(), n, w, h)
+        hip_ctx.synchronize()
+        assert np.array_equal(d_dst.cpu().numpy()[:n * w * h].reshape(n, h, w), want), (w, h)
