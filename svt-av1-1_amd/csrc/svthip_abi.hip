@@ -768,6 +768,7 @@ int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx* ctx, const uint8_t* d
         return fail(SVTHIP_ERR_BAD_PARAMETER, "not an AV1 block size%s (width %d)", "", (int)width);
     if (n_blocks == 0) return SVTHIP_OK;
     if (!d_src0 || !d_src1 || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if (reinterpret_cast<uintptr_t>(d_desc) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !getenv("SVTHIP_CONVOLVE_VALU")) {
         HIP_TRY(svthip::launch_av1_convolve_compound_mfma(d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width,
