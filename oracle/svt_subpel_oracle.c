@@ -406,7 +406,8 @@ void orc_subpel_refine209_batch(const uint8_t *src_plane, uint32_t src_stride, c
  * QuarterPelCompensation :4818-4920, Sort3Elements :5434-5463).
  *
  * Pinned against the reference's own MotionEstimateLcu for integer MVs (sub-pel disabled) in
- * tests/test_hme_vs_ref.py; the fractional-position buffer selection below is restated from the source only.
+ * tests/test_hme_vs_ref.py; the fractional-position buffer selection below is pinned against the reference's own
+ * BiPredictionSearch for arbitrary quarter-pel vectors in tests/test_bipred_vs_ref.py (oracle/ref_bipred_driver.c).
  * ------------------------------------------------------------------------------------------------------------ */
 
 /* prediction sample of one list at fractional position `frac` = (x_mv & 3) + ((y_mv & 3) << 2), integer position (x,y)
