@@ -275,7 +275,50 @@ def pa_sadloop_fixture():
     np.savez_compressed(os.path.join(HERE, "pa_sadloop.npz"), **out)
 
 
+def bipred_frac_fixture():
+    """BiPredictionSearch of the reference (oracle/ref_bipred_driver.c) for random quarter-pel vector pairs of every PU of a 128x128 picture's
+    4 SBs, 85 and 209 PUs: inputs (pictures, descriptors, vectors) and the bi-prediction distortions."""
+    import ctypes as C
+    me = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsvtref_me.so"), mode=os.RTLD_LAZY)
+    me.ref_bipred_search.restype = C.c_int
+    me.ref_bipred_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_void_p]
+    w, h = 128, 128
+    lumas = [synth.synth_luma(w, h, t) for t in (3, 0, 7)]
+    cur, r0, r1 = (synth.PaPicture(x) for x in lumas)
+    rng = np.random.default_rng(31)
+    n_sb = 4
+    d0 = svtav1_hip.make_fullpel_desc(cur, r0, rng.integers(-20, 21, (n_sb, 2)), 64, 64)
+    d1 = svtav1_hip.make_fullpel_desc(cur, r1, rng.integers(-20, 21, (n_sb, 2)), 40, 23)
+    S = cur.full.shape[1]
+    out = dict(cur=lumas[0], ref0=lumas[1], ref1=lumas[2], desc0=d0, desc1=d1)
+
+    def vectors(desc, n_pu):
+        xo, yo, sw, sh = (int(v) for v in desc[2:6])
+        x = 4 * (xo + rng.integers(0, sw, n_pu)) + rng.integers(-3, 4, n_pu)
+        y = 4 * (yo + rng.integers(0, sh, n_pu)) + rng.integers(-3, 4, n_pu)
+        return ((y.astype(np.int64) & 0xffff) << 16 | (x.astype(np.int64) & 0xffff)).astype(np.uint32)
+
+    for n_pu in (85, 209):
+        mv0 = np.stack([vectors(d0[i], n_pu) for i in range(n_sb)])
+        mv1 = np.stack([vectors(d1[i], n_pu) for i in range(n_sb)])
+        sad = np.zeros((n_sb, n_pu), np.uint32)
+        for i in range(n_sb):
+            geo = np.array([d0[i][2], d0[i][3], d0[i][4], d0[i][5], d1[i][2], d1[i][3], d1[i][4], d1[i][5]], np.int32)
+            o = np.zeros(n_pu, np.uint32)
+            ref0_00 = int(d0[i][1]) - (int(d0[i][3]) * S + int(d0[i][2]))
+            ref1_00 = int(d1[i][1]) - (int(d1[i][3]) * S + int(d1[i][2]))
+            m0, m1 = np.ascontiguousarray(mv0[i]), np.ascontiguousarray(mv1[i])
+            rc = me.ref_bipred_search(cur.full.ctypes.data + int(d0[i][0]), S, r0.full.ctypes.data + ref0_00, S, r1.full.ctypes.data + ref1_00, S,
+                                      geo.ctypes.data, m0.ctypes.data, m1.ctypes.data, n_pu, 0, o.ctypes.data)
+            assert rc == 0
+            sad[i] = o
+        out[f"mv0_{n_pu}"], out[f"mv1_{n_pu}"], out[f"bisad_{n_pu}"] = mv0, mv1, sad
+    np.savez_compressed(os.path.join(HERE, "bipred_frac.npz"), **out)
+
+
 if __name__ == "__main__":
+    bipred_frac_fixture()
     ois_fixture()
     convolve_fixture()
     pa_sadloop_fixture()

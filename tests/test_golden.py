@@ -362,3 +362,44 @@ def test_hip_convolve_compound_matches_golden(hip_ctx):
         hip_ctx.av1_convolve_compound_batch_dev(d0.data_ptr(), S, d1.data_ptr(), S, d_dst.data_ptr(), w, d_desc.data_ptr(), n, w, h)
         hip_ctx.synchronize()
         assert np.array_equal(d_dst.cpu().numpy()[:n * w * h].reshape(n, h, w), want), (w, h)
+
+
+# ---- bi-prediction for fractional vectors (the reference's own BiPredictionSearch, row a13) ----
+def _bipred_inputs(g):
+    cur, r0, r1 = (synth.PaPicture(g[k]) for k in ("cur", "ref0", "ref1"))
+    return cur, r0, r1, g["desc0"], g["desc1"]
+
+
+@pytest.mark.parametrize("n_pu", [85, 209])
+def test_oracle_bipred_fractional_matches_golden(oracle, n_pu):
+    g = _load("bipred_frac.npz")
+    cur, r0, r1, d0, d1 = _bipred_inputs(g)
+    S = cur.full.shape[1]
+    big = np.full(g[f"mv0_{n_pu}"].shape, 0x00ffffff, np.uint32)
+    res = oracle.bipred_pack_batch(cur.full, S, r0.full, S, d0, big, g[f"mv0_{n_pu}"], r1.full, S, d1, big, g[f"mv1_{n_pu}"], bipred_8x8=True, n_pu=n_pu)
+    assert (res["direction"][:, :, 0] == 2).all() and np.array_equal(res["distortion"][:, :, 0], g[f"bisad_{n_pu}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pu", [85, 209])
+def test_hip_bipred_fractional_matches_golden(hip_ctx, n_pu):
+    torch = pytest.importorskip("torch")
+    g = _load("bipred_frac.npz")
+    cur, r0, r1, d0, d1 = _bipred_inputs(g)
+    S = cur.full.shape[1]
+    n_sb = d0.shape[0]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")  # noqa: E731
+    pad = np.zeros(256, np.uint8)
+    d_cur, d_r0, d_r1 = (dev(np.concatenate([p.full.reshape(-1), pad])) for p in (cur, r0, r1))
+    big = np.full((n_sb, n_pu), 0x00ffffff, np.uint32)
+    d_big, d_m0, d_m1, d_d0, d_d1 = dev(big), dev(g[f"mv0_{n_pu}"]), dev(g[f"mv1_{n_pu}"]), dev(d0), dev(d1)
+    d_out = torch.zeros(n_sb * n_pu * 24, dtype=torch.uint8, device="cuda:0")
+    args = (d_cur.data_ptr(), S, d_r0.data_ptr(), S, d_d0.data_ptr(), d_r1.data_ptr(), S, d_d1.data_ptr(), n_sb, 64, 64, d_big.data_ptr(), d_m0.data_ptr(),
+            d_big.data_ptr(), d_m1.data_ptr(), 2, d_out.data_ptr())
+    if n_pu == 85:
+        hip_ctx.bipred_pack_dev(*args, bipred_8x8=True)
+    else:
+        hip_ctx.bipred_pack209_dev(*args)
+    hip_ctx.synchronize()
+    res = d_out.cpu().numpy().view(svtav1_hip.ME_CU_RESULT_DTYPE).reshape(n_sb, n_pu)
+    assert (res["direction"][:, :, 0] == 2).all() and np.array_equal(res["distortion"][:, :, 0], g[f"bisad_{n_pu}"])
