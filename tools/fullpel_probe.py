@@ -6,10 +6,11 @@ import numpy as np, torch
 import svtav1_hip
 import bench
 
-pool, stride, desc, _ = bench.build_pool(12, 0)
 dev = torch.device("cuda:0")
-d_pool = torch.from_numpy(pool).to(dev)
 ctx = svtav1_hip.Context(0)
+d_pool, pdesc = bench.device_picture_pool(ctx, 13, 1920, 1080, dev)
+stride = pdesc[0].full_stride
+desc = bench.zero_centred_desc(pdesc[1:13], pdesc[0:12], svtav1_hip.sb_origins(1920, 1080), 1920, 1080)
 sizes = [int(a) for a in sys.argv[1:]] or [256, 512, 768, 1536, 3072, 4080, 4608, 6120]
 for n in sizes:
     d = desc[:n]
