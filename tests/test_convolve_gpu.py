@@ -191,3 +191,66 @@ def test_convolve_compound_every_block_size(hip_ctx, oracle, size):
         finally:
             del os.environ["SVTHIP_CONVOLVE_VALU"]
         assert np.array_equal(got2, want), size
+
+
+def test_convolve_1080p_all_blocks_two_kernels_and_oracle_sample(hip_ctx, oracle):
+    """BASELINE configs[2] shape at full size: every 64x64 block of a 1080p frame at 24 phase / filter combinations (12 240 blocks), uni- and
+    bi-predicted.  Size-independent checks: the matrix-core kernel and the VALU kernel (independent implementations) agree on every byte,
+    phase (0, 0) returns the source block, and a 300-block sample equals the oracle."""
+    torch = pytest.importorskip("torch")
+    import os
+    from svtav1_hip import synth
+    w = h = 64
+    pics = [synth.PaPicture(synth.synth_luma(1920, 1080, t)) for t in (1, 4)]
+    S = pics[0].full.shape[1]
+    nbx, nby, n_ph = 30, 16, 24          # the 17th SB row is 56 rows high: whole 64x64 blocks only
+    n = nbx * nby * n_ph
+    rng = np.random.default_rng(12)
+    i = np.arange(n)
+    blk, ph = i // n_ph, i % n_ph
+    base = (68 + (blk // nbx) * 64) * S + 68 + (blk % nbx) * 64
+    mvx, mvy = rng.integers(-30, 31, n), rng.integers(-30, 31, n)
+    d = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    d["src_offset"] = base + mvy * S + mvx
+    d["dst_offset"] = i * 4096
+    d["subpel_x"], d["subpel_y"] = rng.integers(0, 16, n), rng.integers(0, 16, n)
+    d["subpel_x"][ph == 0] = 0; d["subpel_y"][ph == 0] = 0
+    d["filter_x"], d["filter_y"] = rng.integers(0, 4, n), rng.integers(0, 4, n)
+    c = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+    c["src0_offset"], c["src1_offset"], c["dst_offset"] = d["src_offset"], base - mvy * S - mvx, d["dst_offset"]
+    c["subpel0"] = d["subpel_x"] | (d["subpel_y"] << 4)
+    c["subpel1"] = rng.integers(0, 256, n)
+    c["filter_x"], c["filter_y"] = d["filter_x"], d["filter_y"]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")  # noqa: E731
+    pad = np.zeros(256, np.uint8)
+    d_s0, d_s1 = dev(np.concatenate([pics[0].full.reshape(-1), pad])), dev(np.concatenate([pics[1].full.reshape(-1), pad]))
+    d_d, d_c = dev(d), dev(c)
+
+    def run(compound):
+        out = torch.zeros(n * 4096, dtype=torch.uint8, device="cuda:0")
+        if compound:
+            hip_ctx.av1_convolve_compound_batch_dev(d_s0.data_ptr(), S, d_s1.data_ptr(), S, out.data_ptr(), 64, d_c.data_ptr(), n, w, h)
+        else:
+            hip_ctx.av1_convolve_sr_batch_dev(d_s0.data_ptr(), S, out.data_ptr(), 64, d_d.data_ptr(), n, w, h)
+        hip_ctx.synchronize()
+        return out.cpu().numpy().reshape(n, 64, 64)
+
+    got = {k: run(k) for k in (False, True)}
+    os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+    try:
+        for k in (False, True):
+            assert np.array_equal(run(k), got[k]), "matrix-core and VALU kernels differ (compound=%s)" % k
+    finally:
+        del os.environ["SVTHIP_CONVOLVE_VALU"]
+    flat = pics[0].full.reshape(-1)
+    for j in np.nonzero(ph == 0)[0][:200]:
+        o = int(d["src_offset"][j])
+        assert np.array_equal(got[False][j], flat[o:o + 64 * S].reshape(64, S)[:, :64])
+    sample = rng.choice(n, 300, replace=False)
+    want = np.zeros((300, 64, 64), np.uint8)
+    ds = d[sample].copy(); ds["dst_offset"] = np.arange(300) * 4096
+    _oracle_batch(oracle, pics[0].full, S, want, 64, ds, w, h)
+    assert np.array_equal(got[False][sample], want)
+    cs = c[sample].copy(); cs["dst_offset"] = np.arange(300) * 4096
+    _oracle_compound(oracle, pics[0].full, S, pics[1].full, S, want, 64, cs, w, h)
+    assert np.array_equal(got[True][sample], want)
