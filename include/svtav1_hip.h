@@ -495,6 +495,15 @@ int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx *ctx, const uint8_t *d
                                                const svthip_convolve_compound_desc *d_desc, uint32_t n_blocks, uint32_t width,
                                                uint32_t height, void *stream);
 
+/* The same two entries for 10-bit video held in 16-bit planes: convolveHbd[..][..][is_compound] = av1_highbd_convolve_{2d,x,y,2d_copy}_sr /
+ * av1_highbd_jnt_convolve_* (Codec/EbInterPrediction.c:530-895) with get_conv_params_no_round(.., bd).  Offsets and strides are in
+ * SAMPLES; d_desc is a svthip_convolve_desc array (compound = 0; d_src1 unused) or a svthip_convolve_compound_desc array (compound != 0).
+ * bit_depth must be 10 (round_0 changes at 12 bits). */
+int32_t svthip_av1_highbd_convolve_batch_dev(svthip_ctx *ctx, const uint16_t *d_src0, uint32_t src0_stride, const uint16_t *d_src1,
+                                             uint32_t src1_stride, uint16_t *d_dst, uint32_t dst_stride, const void *d_desc,
+                                             int32_t compound, uint32_t n_blocks, uint32_t width, uint32_t height, uint32_t bit_depth,
+                                             void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batching layer for the transform / quantisation callers.  The reference calls its T/Q kernels one TU and one
  * transform type at a time from ProductFullLoopTxSearch (Codec/EbFullLoop.c:1138-1352: for every tx_type candidate of a TU:

@@ -109,7 +109,7 @@ gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_convol
 gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_ois_driver.c" -o "$OUT/obj/ref_ois_driver.o"
 # the reference's bi-prediction search for chosen quarter-pel vectors (BiPredictionSearch and everything under it)
 gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_bipred_driver.c" -o "$OUT/obj/ref_bipred_driver.o"
-printf '{ global: ref_me_lcu_run; ref_interp_region; ref_fullpel_search_209pu; ref_halfpel_ssd_leaf; ref_halfpel_sad_leaf; ref_quarterpel_ssd_leaf; ref_quarterpel_sad_leaf; generate_padding; generate_padding16_bit; Decimation2D; ref_build_quantizer_rows; ref_scan_order; ref_av1_convolve_sr; ref_av1_convolve_compound; ref_ois_predict; ref_ois_search_picture; ref_bipred_search; local: *; };\n' > "$OUT/obj/me.map"
+printf '{ global: ref_me_lcu_run; ref_interp_region; ref_fullpel_search_209pu; ref_halfpel_ssd_leaf; ref_halfpel_sad_leaf; ref_quarterpel_ssd_leaf; ref_quarterpel_sad_leaf; generate_padding; generate_padding16_bit; Decimation2D; ref_build_quantizer_rows; ref_scan_order; ref_av1_convolve_sr; ref_av1_convolve_compound; ref_av1_highbd_convolve_sr; ref_av1_highbd_convolve_compound; ref_ois_predict; ref_ois_search_picture; ref_bipred_search; local: *; };\n' > "$OUT/obj/me.map"
 gcc -shared -o "$OUT/libsvtref_me.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_me_lcu_driver.o" "$OUT/obj/ref_fullpel209_driver.o" "$OUT/obj/ref_subpel_leaf_driver.o" "$OUT/obj/ref_quant_tables_driver.o" "$OUT/obj/ref_convolve_driver.o" "$OUT/obj/ref_ois_driver.o" "$OUT/obj/ref_bipred_driver.o" \
     -Wl,--gc-sections -Wl,--version-script="$OUT/obj/me.map" -lm -lpthread
 echo "built $OUT/libsvtref_me.so (unresolved by design: $(nm -D "$OUT/libsvtref_me.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"

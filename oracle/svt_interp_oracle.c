@@ -144,6 +144,94 @@ void orc_av1_convolve_compound_batch(const uint8_t *src0, int32_t src0_stride, c
     }
 }
 
+/* ---- 10-bit video in 16-bit planes: av1_highbd_convolve_*_sr_c (:530-660) and av1_highbd_jnt_convolve_*_c (:661-880).  The same arithmetic
+ * with bd in the offsets: pass-1 offset 1 << (bd + 6), offset_bits = bd + 11, round_offset = (1 << (bd + 4)) + (1 << (bd + 3)) in the
+ * compound forms; round_0 = 3 holds for bd <= 10 (get_conv_params_no_round raises it only from bd = 12). ---- */
+static uint16_t clip_bd(int v, int bd) { const int m = (1 << bd) - 1; return (uint16_t)(v < 0 ? 0 : (v > m ? m : v)); }
+
+static void hbd_list(const uint16_t *src, int32_t src_stride, int32_t *res, int32_t w, int32_t h, const int16_t *fx, const int16_t *fy, int subpel_x,
+                     int subpel_y, int bd, int compound)
+{
+    const int ro = (1 << (bd + 4)) + (1 << (bd + 3));
+    if (subpel_x && subpel_y) {
+        static int16_t im[(128 + 7) * 128];
+        const uint16_t *s = src - 3 * src_stride;
+        for (int y = 0; y < h + 7; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << (bd + 6);
+                for (int k = 0; k < 8; k++) sum += fx[k] * s[y * src_stride + x - 3 + k];
+                im[y * w + x] = (int16_t)((sum + 4) >> 3);
+            }
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t sum = 1 << (bd + 11);
+                for (int k = 0; k < 8; k++) sum += fy[k] * im[(y + k) * w + x];
+                res[y * w + x] = compound ? (int32_t)(uint16_t)((sum + 64) >> 7) : ((sum + 1024) >> 11) - ((1 << bd) + (1 << (bd - 1)));
+            }
+    } else if (subpel_y) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t r = 0;
+                for (int k = 0; k < 8; k++) r += fy[k] * src[(y - 3 + k) * src_stride + x];
+                res[y * w + x] = compound ? (int32_t)(uint16_t)((((r * 16) + 64) >> 7) + ro) : ((r + 64) >> 7);
+            }
+    } else if (subpel_x) {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int32_t r = 0;
+                for (int k = 0; k < 8; k++) r += fx[k] * src[y * src_stride + x - 3 + k];
+                r = (r + 4) >> 3;
+                res[y * w + x] = compound ? (int32_t)(uint16_t)(r + ro) : ((r + 8) >> 4);
+            }
+    } else {
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) res[y * w + x] = compound ? (int32_t)(uint16_t)((src[y * src_stride + x] << 4) + ro) : src[y * src_stride + x];
+    }
+}
+
+void orc_av1_highbd_convolve_sr(const uint16_t *src, int32_t src_stride, uint16_t *dst, int32_t dst_stride, int32_t w, int32_t h, int filter_x,
+                                int filter_y, int subpel_x, int subpel_y, int bd)
+{
+    static int32_t r[128 * 128];
+    hbd_list(src, src_stride, r, w, h, kFilters[filter_index(filter_x, w)][subpel_x & 15], kFilters[filter_index(filter_y, h)][subpel_y & 15], subpel_x,
+             subpel_y, bd, 0);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) dst[y * dst_stride + x] = clip_bd(r[y * w + x], bd);
+}
+
+void orc_av1_highbd_convolve_compound(const uint16_t *src0, int32_t src0_stride, const uint16_t *src1, int32_t src1_stride, uint16_t *dst,
+                                      int32_t dst_stride, int32_t w, int32_t h, int filter_x, int filter_y, int subpel_x0, int subpel_y0,
+                                      int subpel_x1, int subpel_y1, int bd)
+{
+    static int32_t r0[128 * 128], r1[128 * 128];
+    const int fxi = filter_index(filter_x, w), fyi = filter_index(filter_y, h), ro = (1 << (bd + 4)) + (1 << (bd + 3));
+    hbd_list(src0, src0_stride, r0, w, h, kFilters[fxi][subpel_x0 & 15], kFilters[fyi][subpel_y0 & 15], subpel_x0, subpel_y0, bd, 1);
+    hbd_list(src1, src1_stride, r1, w, h, kFilters[fxi][subpel_x1 & 15], kFilters[fyi][subpel_y1 & 15], subpel_x1, subpel_y1, bd, 1);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) dst[y * dst_stride + x] = clip_bd((((r0[y * w + x] + r1[y * w + x]) >> 1) - ro + 8) >> 4, bd);
+}
+
+/* batch forms (offsets and strides in SAMPLES; descriptors as in the 8-bit batches) */
+void orc_av1_highbd_convolve_sr_batch(const uint16_t *src, int32_t src_stride, uint16_t *dst, int32_t dst_stride, const uint32_t *desc, uint32_t n,
+                                      int32_t w, int32_t h, int bd)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *d = desc + 4 * i;
+        orc_av1_highbd_convolve_sr(src + d[0], src_stride, dst + d[1], dst_stride, w, h, (d[2] >> 16) & 255, (d[2] >> 24) & 255, d[2] & 15, (d[2] >> 8) & 15,
+                                   bd);
+    }
+}
+
+void orc_av1_highbd_convolve_compound_batch(const uint16_t *src0, int32_t src0_stride, const uint16_t *src1, int32_t src1_stride, uint16_t *dst,
+                                            int32_t dst_stride, const uint32_t *desc, uint32_t n, int32_t w, int32_t h, int bd)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *d = desc + 4 * i, p = d[3];
+        orc_av1_highbd_convolve_compound(src0 + d[0], src0_stride, src1 + d[1], src1_stride, dst + d[2], dst_stride, w, h, (p >> 16) & 255,
+                                         (p >> 24) & 255, p & 15, (p >> 4) & 15, (p >> 8) & 15, (p >> 12) & 15, bd);
+    }
+}
+
 /* the batch the device entry takes: desc = { src_offset, dst_offset, subpel_x | subpel_y << 8 | filter_x << 16 | filter_y << 24, 0 } */
 void orc_av1_convolve_sr_batch(const uint8_t *src, int32_t src_stride, uint8_t *dst, int32_t dst_stride, const uint32_t *desc, uint32_t n,
                                int32_t w, int32_t h)

@@ -41,11 +41,14 @@ __device__ __forceinline__ int filter_index(int f, int size)
 
 // COMPOUND: descriptors are svthip_convolve_compound_desc; both lists are run (list 0's 16-bit results parked in LDS) and averaged like
 // av1_inter_prediction's BI_PRED path: av1_jnt_convolve_* with round_1 = 7, round_offset = 6144, round_bits = 4 (EbInterPrediction.c:290-528).
-template <int RB, bool COMPOUND>
+// HBD: 16-bit planes holding bd-bit samples (offsets and strides in SAMPLES): av1_highbd_convolve_*_sr_c / av1_highbd_jnt_convolve_*_c
+// (:530-880), the same arithmetic with bd in the offsets.
+template <int RB, bool COMPOUND, bool HBD>
 __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __restrict__ src0, uint32_t src0_stride, const uint8_t* __restrict__ src1,
                                                               uint32_t src1_stride, uint8_t* __restrict__ dst, uint32_t dst_stride,
-                                                              const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h, int blocks_per_wg)
+                                                              const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h, int blocks_per_wg, int bd)
 {
+    constexpr int SB = HBD ? 2 : 1;  // bytes per sample
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     lds_u8* im = (lds_u8*)smem;  // int16 [blocks_per_wg][h + 7][w]
     const int tid = threadIdx.x;
@@ -69,12 +72,50 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
             const int fxt = COMPOUND ? (int)((d.w >> 16) & 255) : (int)((d.z >> 16) & 255);
             const int rows = sy ? rows_im : h;  // a vertical filter needs 3 rows above and 4 below
             if (r >= rows) continue;
-            const uint8_t* p = src + soff + (int64_t)(r - (sy ? 3 : 0)) * src_stride + c - (sx ? 3 : 0);
+            const uint8_t* p = src + ((int64_t)soff + (int64_t)(r - (sy ? 3 : 0)) * src_stride + c - (sx ? 3 : 0)) * SB;
             const uintptr_t a = reinterpret_cast<uintptr_t>(p);
             const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
             const uint32_t sh = (uint32_t)(a & 3u);
             uint32_t o01, o23;  // four int16
-            if (sx) {
+            if (HBD) {
+                // samples p[0..10] as halfwords of six dwords (a plane of 16-bit samples is 2-byte aligned: sh is 0 or 2)
+                uint32_t e[6];
+                const int nq = sx ? 6 : 2;  // without a horizontal filter only the four samples themselves are touched
+#pragma unroll
+                for (int k = 0; k < 6; k++) e[k] = k < nq ? q[k] : 0u;
+                if (sh) {
+                    const uint32_t qn = q[nq];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) e[k] = __builtin_amdgcn_alignbyte(k + 1 < nq ? e[k + 1] : qn, e[k], 2);
+                    e[5] = __builtin_amdgcn_alignbyte(qn, e[5], 2);
+                }
+                if (sx) {
+                    const int fi = filter_index(fxt, w);
+                    const uint32_t flo = kInterp[fi][sx][0], fhi = kInterp[fi][sx][1];
+                    int f[8], sm[11];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        f[k] = (int)(int8_t)(flo >> (8 * k));
+                        f[4 + k] = (int)(int8_t)(fhi >> (8 * k));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 11; k++) sm[k] = (int)((e[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+                    const int bias = (sy ? (1 << (bd + 6)) : 0) + 4;  // 2-D: sum = (1 << (bd + FILTER_BITS - 1)) + sum f p; then (sum + 4) >> 3
+                    int v[4];
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; i4++) {
+                        int acc = bias;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) acc += __mul24(f[k], sm[i4 + k]);
+                        v[i4] = acc >> 3;
+                    }
+                    o01 = ((uint32_t)v[0] & 0xffffu) | ((uint32_t)v[1] << 16);
+                    o23 = ((uint32_t)v[2] & 0xffffu) | ((uint32_t)v[3] << 16);
+                } else {
+                    o01 = e[0];
+                    o23 = e[1];
+                }
+            } else if (sx) {
                 const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                 const uint32_t e0 = __builtin_amdgcn_alignbyte(q1, q0, sh) ^ 0x80808080u, e1 = __builtin_amdgcn_alignbyte(q2, q1, sh) ^ 0x80808080u,
                                e2 = __builtin_amdgcn_alignbyte(q3, q2, sh) ^ 0x80808080u;  // bytes p[0..11] - 128
@@ -112,6 +153,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
             const int fyt = COMPOUND ? (int)((d.w >> 24) & 255) : (int)((d.z >> 24) & 255);
             const uint32_t doff = COMPOUND ? d.z : d.y;
             int f[8], c0, shift, sub;
+            const int round_offset = (1 << (bd + 4)) + (1 << (bd + 3)), pix_max = (1 << bd) - 1;
             if (sy) {
                 const int fi = filter_index(fyt, h);
                 const uint32_t flo = kInterp[fi][sy][0], fhi = kInterp[fi][sy][1];
@@ -121,11 +163,11 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
                     f[4 + k] = (int)(int8_t)(fhi >> (8 * k));
                 }
                 if (!COMPOUND) {
-                    if (sx) { c0 = (1 << 19) + (1 << 10); shift = 11; sub = (1 << 8) + (1 << 7); }  // 2-D: offset_bits = 19, round_1 = 11
+                    if (sx) { c0 = (1 << (bd + 11)) + (1 << 10); shift = 11; sub = (1 << bd) + (1 << (bd - 1)); }  // 2-D: offset_bits = bd + 11, round_1 = 11
                     else { c0 = 64; shift = 7; sub = 0; }                                          // y only: ROUND_POWER_OF_TWO(res, FILTER_BITS)
                 } else {
-                    if (sx) { c0 = (1 << 19) + 64; shift = 7; sub = 0; }  // ROUND(sum, round_1 = 7)
-                    else { c0 = 4; shift = 3; sub = -6144; }               // ROUND(res << 4, 7) + round_offset
+                    if (sx) { c0 = (1 << (bd + 11)) + 64; shift = 7; sub = 0; }  // ROUND(sum, round_1 = 7)
+                    else { c0 = 4; shift = 3; sub = -round_offset; }             // ROUND(res << 4, 7) + round_offset
                 }
             } else {
 #pragma unroll
@@ -135,7 +177,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
                     else { c0 = 0; shift = 0; }     // copy
                 } else {
                     if (!sx) f[0] = 16;             // copy: (p << 4) + round_offset;  x only: ROUND(sum, 3) + round_offset
-                    c0 = 6144; shift = 0;
+                    c0 = round_offset; shift = 0;
                 }
                 sub = 0;
             }
@@ -148,7 +190,7 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
                 lo[j] = (int)(int16_t)(v & 0xffffu);
                 hi[j] = (int)v >> 16;
             }
-            uint8_t* out = dst + doff + (size_t)y0 * dst_stride + 2 * cp;
+            uint8_t* out = dst + ((size_t)doff + (size_t)y0 * dst_stride + 2 * cp) * SB;
             lds_u32* park = reinterpret_cast<lds_u32*>(res0 + g * h * w * 2) + cp;  // dword = 2 uint16 columns; row pitch w2 dwords
 #pragma unroll
             for (int j = 0; j < RB; j++) {
@@ -166,13 +208,18 @@ __global__ void __launch_bounds__(256) av1_convolve_sr_kernel(const uint8_t* __r
                         continue;
                     }
                     const uint32_t pv = park[(y0 + j) * w2];
-                    r0 = ((((int)(pv & 0xffffu) + (r0 & 0xffff)) >> 1) - 6144 + 8) >> 4;  // CONV_BUF_TYPE is uint16_t
-                    r1 = ((((int)(pv >> 16) + (r1 & 0xffff)) >> 1) - 6144 + 8) >> 4;
+                    r0 = ((((int)(pv & 0xffffu) + (r0 & 0xffff)) >> 1) - round_offset + 8) >> 4;  // CONV_BUF_TYPE is uint16_t
+                    r1 = ((((int)(pv >> 16) + (r1 & 0xffff)) >> 1) - round_offset + 8) >> 4;
                 }
-                r0 = min(max(r0, 0), 255);
-                r1 = min(max(r1, 0), 255);
-                out[(size_t)j * dst_stride] = (uint8_t)r0;
-                out[(size_t)j * dst_stride + 1] = (uint8_t)r1;
+                r0 = min(max(r0, 0), pix_max);
+                r1 = min(max(r1, 0), pix_max);
+                if (HBD) {
+                    reinterpret_cast<uint16_t*>(out)[(size_t)j * dst_stride] = (uint16_t)r0;
+                    reinterpret_cast<uint16_t*>(out)[(size_t)j * dst_stride + 1] = (uint16_t)r1;
+                } else {
+                    out[(size_t)j * dst_stride] = (uint8_t)r0;
+                    out[(size_t)j * dst_stride + 1] = (uint8_t)r1;
+                }
             }
         }
         if (COMPOUND) __syncthreads();  // list 1's pass 1 overwrites the intermediate rows
@@ -189,19 +236,29 @@ bool convolve_size_valid(int w, int h)
     return r <= 4 && !(w == 128 && h == 32) && !(w == 32 && h == 128);
 }
 
+namespace {
+template <bool COMPOUND, bool HBD>
+hipError_t launch_valu(const void* src0, uint32_t src0_stride, const void* src1, uint32_t src1_stride, void* dst, uint32_t dst_stride, const void* desc,
+                       uint32_t n_blocks, int w, int h, int bd, hipStream_t s)
+{
+    const int per = w * h >= 4096 ? 1 : 4096 / (w * h);
+    const size_t lds = COMPOUND ? convolve_compound_lds_bytes(w, h) : (size_t)per * (h + 7) * w * 2;
+    const uint32_t grid = (n_blocks + per - 1) / per;
+    const uint8_t *a = static_cast<const uint8_t*>(src0), *b = static_cast<const uint8_t*>(src1);
+    if (h >= 8)
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<8, COMPOUND, HBD>), dim3(grid), dim3(256), lds, s, a, src0_stride, b, src1_stride,
+                           static_cast<uint8_t*>(dst), dst_stride, reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per, bd);
+    else
+        hipLaunchKernelGGL((av1_convolve_sr_kernel<4, COMPOUND, HBD>), dim3(grid), dim3(256), lds, s, a, src0_stride, b, src1_stride,
+                           static_cast<uint8_t*>(dst), dst_stride, reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per, bd);
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_av1_convolve_sr(const uint8_t* src, uint32_t src_stride, uint8_t* dst, uint32_t dst_stride, const svthip_convolve_desc* desc,
                                   uint32_t n_blocks, int w, int h, hipStream_t s)
 {
-    const int per = w * h >= 4096 ? 1 : 4096 / (w * h);
-    const size_t lds = (size_t)per * (h + 7) * w * 2;
-    const uint32_t grid = (n_blocks + per - 1) / per;
-    if (h >= 8)
-        hipLaunchKernelGGL((av1_convolve_sr_kernel<8, false>), dim3(grid), dim3(256), lds, s, src, src_stride, src, src_stride, dst, dst_stride,
-                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
-    else
-        hipLaunchKernelGGL((av1_convolve_sr_kernel<4, false>), dim3(grid), dim3(256), lds, s, src, src_stride, src, src_stride, dst, dst_stride,
-                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
-    return hipGetLastError();
+    return launch_valu<false, false>(src, src_stride, src, src_stride, dst, dst_stride, desc, n_blocks, w, h, 8, s);
 }
 
 size_t convolve_compound_lds_bytes(int w, int h)
@@ -210,25 +267,28 @@ size_t convolve_compound_lds_bytes(int w, int h)
     return (size_t)per * ((h + 7) * w * 2 + h * w * 2);
 }
 
-// the two instantiations whose dynamic LDS can pass 64 KB (128-wide blocks): svthip_abi.hip raises their limit once per device
-const void* convolve_compound_kernel_ptr(int rb)
+// the instantiations whose dynamic LDS can pass 64 KB (128-wide compound blocks): svthip_abi.hip raises their limit once per device
+const void* convolve_compound_kernel_ptr(int which)
 {
-    return rb == 8 ? reinterpret_cast<const void*>(&av1_convolve_sr_kernel<8, true>) : reinterpret_cast<const void*>(&av1_convolve_sr_kernel<4, true>);
+    switch (which) {
+    case 0: return reinterpret_cast<const void*>(&av1_convolve_sr_kernel<8, true, false>);
+    case 1: return reinterpret_cast<const void*>(&av1_convolve_sr_kernel<4, true, false>);
+    case 2: return reinterpret_cast<const void*>(&av1_convolve_sr_kernel<8, true, true>);
+    default: return reinterpret_cast<const void*>(&av1_convolve_sr_kernel<4, true, true>);
+    }
 }
 
 hipError_t launch_av1_convolve_compound(const uint8_t* src0, uint32_t src0_stride, const uint8_t* src1, uint32_t src1_stride, uint8_t* dst,
                                         uint32_t dst_stride, const svthip_convolve_compound_desc* desc, uint32_t n_blocks, int w, int h, hipStream_t s)
 {
-    const int per = w * h >= 4096 ? 1 : 4096 / (w * h);
-    const size_t lds = convolve_compound_lds_bytes(w, h);
-    const uint32_t grid = (n_blocks + per - 1) / per;
-    if (h >= 8)
-        hipLaunchKernelGGL((av1_convolve_sr_kernel<8, true>), dim3(grid), dim3(256), lds, s, src0, src0_stride, src1, src1_stride, dst, dst_stride,
-                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
-    else
-        hipLaunchKernelGGL((av1_convolve_sr_kernel<4, true>), dim3(grid), dim3(256), lds, s, src0, src0_stride, src1, src1_stride, dst, dst_stride,
-                           reinterpret_cast<const uint4*>(desc), n_blocks, w, h, per);
-    return hipGetLastError();
+    return launch_valu<true, false>(src0, src0_stride, src1, src1_stride, dst, dst_stride, desc, n_blocks, w, h, 8, s);
+}
+
+hipError_t launch_av1_highbd_convolve(const uint16_t* src0, uint32_t src0_stride, const uint16_t* src1, uint32_t src1_stride, uint16_t* dst,
+                                      uint32_t dst_stride, const void* desc, bool compound, uint32_t n_blocks, int w, int h, int bd, hipStream_t s)
+{
+    return compound ? launch_valu<true, true>(src0, src0_stride, src1, src1_stride, dst, dst_stride, desc, n_blocks, w, h, bd, s)
+                    : launch_valu<false, true>(src0, src0_stride, src0, src0_stride, dst, dst_stride, desc, n_blocks, w, h, bd, s);
 }
 
 }  // namespace svthip

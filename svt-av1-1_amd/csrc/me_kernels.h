@@ -121,7 +121,9 @@ hipError_t launch_av1_convolve_compound_mfma(const uint8_t* src0, uint32_t src0_
 hipError_t launch_av1_convolve_compound(const uint8_t* src0, uint32_t src0_stride, const uint8_t* src1, uint32_t src1_stride, uint8_t* dst,
                                         uint32_t dst_stride, const svthip_convolve_compound_desc* desc, uint32_t n_blocks, int w, int h, hipStream_t s);
 size_t convolve_compound_lds_bytes(int w, int h);
-const void* convolve_compound_kernel_ptr(int rb);
+const void* convolve_compound_kernel_ptr(int which);  // 0..3
+hipError_t launch_av1_highbd_convolve(const uint16_t* src0, uint32_t src0_stride, const uint16_t* src1, uint32_t src1_stride, uint16_t* dst,
+                                      uint32_t dst_stride, const void* desc, bool compound, uint32_t n_blocks, int w, int h, int bd, hipStream_t s);
 size_t sad_loop_qsad_slice_bytes(int w, int h, int sw, int sh, int k);
 hipError_t launch_sad_loop_qsad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t ref_stride_raw,
                                 const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, int slice_bytes,

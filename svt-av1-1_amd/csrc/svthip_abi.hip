@@ -57,8 +57,9 @@ void set_kernel_attrs(int device)
     const void* kernels[] = {reinterpret_cast<const void*>(svthip::fullpel85_kernel),  reinterpret_cast<const void*>(svthip::fullpel209_kernel),
                              reinterpret_cast<const void*>(svthip::subpel85_kernel),   reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
                              reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
-                             reinterpret_cast<const void*>(svthip::subpel_planes_kernel), svthip::convolve_compound_kernel_ptr(8),
-                             svthip::convolve_compound_kernel_ptr(4)};
+                             reinterpret_cast<const void*>(svthip::subpel_planes_kernel), svthip::convolve_compound_kernel_ptr(0),
+                             svthip::convolve_compound_kernel_ptr(1),                     svthip::convolve_compound_kernel_ptr(2),
+                             svthip::convolve_compound_kernel_ptr(3)};
     hipError_t st = hipSuccess;
     for (const void* k : kernels) {
         hipFuncAttributes fa;
@@ -776,6 +777,25 @@ int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx* ctx, const uint8_t* d
         return SVTHIP_OK;
     }
     HIP_TRY(svthip::launch_av1_convolve_compound(d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
+    return SVTHIP_OK;
+}
+
+int32_t svthip_av1_highbd_convolve_batch_dev(svthip_ctx* ctx, const uint16_t* d_src0, uint32_t src0_stride, const uint16_t* d_src1, uint32_t src1_stride,
+                                             uint16_t* d_dst, uint32_t dst_stride, const void* d_desc, int32_t compound, uint32_t n_blocks, uint32_t width,
+                                             uint32_t height, uint32_t bit_depth, void* stream)
+{
+    ENTER(ctx);
+    if (!svthip::convolve_size_valid((int)width, (int)height))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "not an AV1 block size%s (width %d)", "", (int)width);
+    if (bit_depth != 10) return fail(SVTHIP_ERR_BAD_PARAMETER, "bit_depth must be 10%s (got %d)", "", (int)bit_depth);
+    if (n_blocks == 0) return SVTHIP_OK;
+    if (!d_src0 || (compound && !d_src1) || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
+    if ((reinterpret_cast<uintptr_t>(d_desc) & 15u) || (reinterpret_cast<uintptr_t>(d_src0) & 1u) || (reinterpret_cast<uintptr_t>(d_src1) & 1u) ||
+        (reinterpret_cast<uintptr_t>(d_dst) & 1u))
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned, planes 2-byte aligned%s", "");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(svthip::launch_av1_highbd_convolve(d_src0, src0_stride, compound ? d_src1 : d_src0, compound ? src1_stride : src0_stride, d_dst, dst_stride,
+                                               d_desc, compound != 0, n_blocks, (int)width, (int)height, (int)bit_depth, s));
     return SVTHIP_OK;
 }
 

@@ -125,6 +125,9 @@ def lib() -> C.CDLL:
     L.svthip_av1_convolve_compound_batch_dev.restype = C.c_int32
     L.svthip_av1_convolve_compound_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                                          C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.svthip_av1_highbd_convolve_batch_dev.restype = C.c_int32
+    L.svthip_av1_highbd_convolve_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                       C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.svthip_sad_loop_batch_dev.restype = C.c_int32
     L.svthip_sad_loop_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -437,6 +440,16 @@ def _av1_convolve_compound_batch_dev(self, d_src0, src0_stride, d_src1, src1_str
 
 
 Context.av1_convolve_compound_batch_dev = _av1_convolve_compound_batch_dev
+
+
+def _av1_highbd_convolve_batch_dev(self, d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, compound, n_blocks, width, height,
+                                   bit_depth=10, stream=None):
+    """10-bit inter prediction in 16-bit planes (offsets / strides in samples); compound selects the descriptor type."""
+    _check(lib().svthip_av1_highbd_convolve_batch_dev(self._h, d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, int(compound),
+                                                      n_blocks, width, height, bit_depth, stream))
+
+
+Context.av1_highbd_convolve_batch_dev = _av1_highbd_convolve_batch_dev
 
 
 def _sad_loop_batch_dev(self, d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, width, height, sw, sh, d_best_sad, d_best_xy,

@@ -254,3 +254,66 @@ def test_convolve_1080p_all_blocks_two_kernels_and_oracle_sample(hip_ctx, oracle
     cs = c[sample].copy(); cs["dst_offset"] = np.arange(300) * 4096
     _oracle_compound(oracle, pics[0].full, S, pics[1].full, S, want, 64, cs, w, h)
     assert np.array_equal(got[True][sample], want)
+
+
+@pytest.mark.parametrize("size", svtav1_hip.AV1_BLOCK_SIZES_WH)
+def test_highbd_convolve_every_block_size(hip_ctx, oracle, size):
+    """10-bit inter prediction in 16-bit planes (av1_highbd_convolve_*_sr / av1_highbd_jnt_convolve_* pair), uni- and bi-predicted, every AV1
+    block size, all case combinations, random and extreme (0 / 1023) samples, odd sample offsets and strides."""
+    torch = pytest.importorskip("torch")
+    w, h = size
+    rng = np.random.default_rng(w * 269 + h)
+    S0, S1, R = 641, 705, 400
+    s0 = rng.integers(0, 1024, (R, S0), dtype=np.uint16)
+    s1 = rng.integers(0, 1024, (R, S1), dtype=np.uint16)
+    s0[:40] = (((np.arange(S0)[None, :] // 2 + np.arange(40)[:, None] // 3) & 1) * 1023).astype(np.uint16)
+    s1[:60, ::2] = 1023; s1[:60, 1::2] = 0
+    cols, rows = 512 // w, 256 // h
+    n = min(cols * rows, 120) - 1
+    slots = rng.permutation(cols * rows)[:n]
+    D = 512 + 1
+    cd = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+    ud = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    for i, sl in enumerate(slots):
+        bx, by = (int(sl) % cols) * w, (int(sl) // cols) * h
+        off = []
+        for S in (S0, S1):
+            sx = min(max(40 + bx + int(rng.integers(-20, 21)), 8), S - w - 8); sy = min(max(40 + by + int(rng.integers(-20, 21)), 8), R - h - 8)
+            off.append(sy * S + sx)
+        ph = [int(v) for v in rng.integers(0, 16, 4)]
+        if i < 16:
+            a, b = i & 3, i >> 2
+            ph = [(ph[0] or 5) if a & 1 else 0, (ph[1] or 9) if a & 2 else 0, (ph[2] or 3) if b & 1 else 0, (ph[3] or 12) if b & 2 else 0]
+        fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        cd[i] = (off[0], off[1], by * D + bx, ph[0] | (ph[1] << 4), ph[2] | (ph[3] << 4), fx, fy)
+        ud[i] = (off[0], by * D + bx, ph[0], ph[1], fx, fy, 0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to("cuda:0")  # noqa: E731
+    pad = np.zeros(64, np.uint16)
+    d0, d1 = dev(np.concatenate([s0.reshape(-1), pad])), dev(np.concatenate([s1.reshape(-1), pad]))
+    A = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int]
+    B = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int]
+    fu, fc = oracle.lib.orc_av1_highbd_convolve_sr_batch, oracle.lib.orc_av1_highbd_convolve_compound_batch
+    fu.restype = None; fu.argtypes = A
+    fc.restype = None; fc.argtypes = B
+    for compound in (False, True):
+        want = np.full((256, D), 0x155, np.uint16)
+        d_dst = dev(want)
+        if compound:
+            dd = np.zeros((n, 4), np.uint32)
+            dd[:, 0], dd[:, 1], dd[:, 2] = cd["src0_offset"], cd["src1_offset"], cd["dst_offset"]
+            dd[:, 3] = cd["subpel0"].astype(np.uint32) | (cd["subpel1"].astype(np.uint32) << 8) | (cd["filter_x"].astype(np.uint32) << 16) | \
+                (cd["filter_y"].astype(np.uint32) << 24)
+            fc(s0.ctypes.data, S0, s1.ctypes.data, S1, want.ctypes.data, D, dd.ctypes.data, n, w, h, 10)
+            d_desc = dev(cd)
+        else:
+            dd = np.zeros((n, 4), np.uint32)
+            dd[:, 0], dd[:, 1] = ud["src_offset"], ud["dst_offset"]
+            dd[:, 2] = ud["subpel_x"].astype(np.uint32) | (ud["subpel_y"].astype(np.uint32) << 8) | (ud["filter_x"].astype(np.uint32) << 16) | \
+                (ud["filter_y"].astype(np.uint32) << 24)
+            fu(s0.ctypes.data, S0, want.ctypes.data, D, dd.ctypes.data, n, w, h, 10)
+            d_desc = dev(ud)
+        hip_ctx.av1_highbd_convolve_batch_dev(d0.data_ptr(), S0, d1.data_ptr(), S1, d_dst.data_ptr(), D, d_desc.data_ptr(), compound, n, w, h, 10)
+        hip_ctx.synchronize()
+        got = d_dst.cpu().numpy().view(np.uint16).reshape(256, D)
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, (size, compound, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])

@@ -109,3 +109,39 @@ def test_compound_matches_reference(oracle, ref, size):
             ref.ref_av1_convolve_compound(*args, x.ctypes.data, w + 3, w, h, fx, fy, *ph)
             orc(*args, y.ctypes.data, w + 3, w, h, fx, fy, *ph)
             assert np.array_equal(x, y), (w, h, fx, fy, ph)
+
+
+@pytest.mark.parametrize("size", BLOCK_SIZES)
+def test_highbd_matches_reference(oracle, ref, size):
+    """10-bit video in 16-bit planes: av1_highbd_convolve_*_sr_c and the av1_highbd_jnt_convolve_* pair (bd = 10) against the oracle:
+    all four cases per list, random and extreme (0 / 1023) pictures."""
+    w, h = size
+    A = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int] * 5
+    B = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_int] * 7
+    for f, at in ((ref.ref_av1_highbd_convolve_sr, A), (oracle.lib.orc_av1_highbd_convolve_sr, A), (ref.ref_av1_highbd_convolve_compound, B),
+                  (oracle.lib.orc_av1_highbd_convolve_compound, B)):
+        f.restype = None
+        f.argtypes = at
+    rng = np.random.default_rng(w * 19 + h)
+    S0, S1 = w + 24, w + 40
+    for kind in range(2):
+        if kind == 0:
+            s0 = rng.integers(0, 1024, (h + 16, S0), dtype=np.uint16); s1 = rng.integers(0, 1024, (h + 16, S1), dtype=np.uint16)
+        else:
+            yy, xx = np.mgrid[0:h + 16, 0:S0]
+            s0 = (((xx // 2 + yy // 3) & 1) * 1023).astype(np.uint16)
+            s1 = np.full((h + 16, S1), 1023, np.uint16); s1[::3] = 0
+        p0, p1 = s0.ctypes.data + 2 * (8 * S0 + 8), s1.ctypes.data + 2 * (8 * S1 + 8)
+        for trial in range(20):
+            fx, fy = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            ph = [int(v) for v in rng.integers(0, 16, 4)]
+            if trial < 16:
+                a, b = trial & 3, trial >> 2
+                ph = [(ph[0] or 5) if a & 1 else 0, (ph[1] or 9) if a & 2 else 0, (ph[2] or 3) if b & 1 else 0, (ph[3] or 12) if b & 2 else 0]
+            x = np.zeros((h, w + 3), np.uint16); y = np.zeros((h, w + 3), np.uint16)
+            ref.ref_av1_highbd_convolve_sr(p0, S0, x.ctypes.data, w + 3, w, h, fx, fy, ph[0], ph[1], 10)
+            oracle.lib.orc_av1_highbd_convolve_sr(p0, S0, y.ctypes.data, w + 3, w, h, fx, fy, ph[0], ph[1], 10)
+            assert np.array_equal(x, y), ("sr", w, h, fx, fy, ph)
+            ref.ref_av1_highbd_convolve_compound(p0, S0, p1, S1, x.ctypes.data, w + 3, w, h, fx, fy, *ph, 10)
+            oracle.lib.orc_av1_highbd_convolve_compound(p0, S0, p1, S1, y.ctypes.data, w + 3, w, h, fx, fy, *ph, 10)
+            assert np.array_equal(x, y), ("compound", w, h, fx, fy, ph)
