@@ -436,7 +436,31 @@ def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):
         algo = px * 6 + n_tu * nc * 6
         out[f"encode_tu16_{nn}x{nn}_bd10"] = {"n_tu": n_tu, "ms": round(ms, 4), "gpix_per_s": round(px / ms / 1e6, 2),
                                             "algorithmic_gbps": round(algo / ms / 1e6, 1)}
-    out["workload"] = "3840x2160: ME = search centres + 64x64 full-pel, 85 PUs, one list, 3 pictures per launch; T/Q = one 10-bit luma frame of TUs"
+    # 10-bit inter prediction of every 64x64 block of the 4K frame at 8 random phase pairs, uni- and bi-predicted
+    S = 3840 + 160
+    ref16 = torch.randint(0, 1024, (S * (2176 + 160),), dtype=torch.int16, device=dev)
+    nbx, nby, n_ph = 60, 34, 8
+    n = nbx * nby * n_ph
+    i = np.arange(n)
+    blk = i // n_ph
+    d = np.zeros(n, dtype=svtav1_hip.CONVOLVE_DESC_DTYPE)
+    d["src_offset"] = (80 + (blk // nbx) * 64) * S + 80 + (blk % nbx) * 64
+    d["dst_offset"] = i * 4096
+    d["subpel_x"], d["subpel_y"] = rng.integers(1, 16, n), rng.integers(1, 16, n)
+    d["filter_x"], d["filter_y"] = rng.integers(0, 4, n), rng.integers(0, 4, n)
+    c = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
+    c["src0_offset"], c["src1_offset"], c["dst_offset"] = d["src_offset"], d["src_offset"] + 3 * S + 5, d["dst_offset"]
+    c["subpel0"], c["subpel1"] = d["subpel_x"] | (d["subpel_y"] << 4), d["subpel_y"] | (d["subpel_x"] << 4)
+    c["filter_x"], c["filter_y"] = d["filter_x"], d["filter_y"]
+    d_d = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_c = torch.from_numpy(c.view(np.uint8).reshape(-1).copy()).to(dev)
+    d_dst = torch.empty(n * 4096, dtype=torch.int16, device=dev)
+    for name, desc_t, comp in (("inter_pred_64x64_bd10", d_d, False), ("inter_pred_64x64_bd10_bipred", d_c, True)):
+        ms = timer.ms(lambda: ctx.av1_highbd_convolve_batch_dev(ref16.data_ptr(), S, ref16.data_ptr(), S, d_dst.data_ptr(), 64, desc_t.data_ptr(), comp, n,
+                                                                64, 64, 10, timer.stream), 5)
+        out[name] = {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2)}
+    out["workload"] = ("3840x2160: ME = search centres + 64x64 full-pel, 85 PUs, one list, 3 pictures per launch; T/Q = one 10-bit luma frame of TUs; "
+                       "inter prediction = every 64x64 block x 8 phase pairs, 10-bit samples")
     return out
 
 
