@@ -40,4 +40,12 @@ __global__ void __launch_bounds__(256) hme_center_kernel(const uint8_t* __restri
                   l0_mv_stride, out_desc, out_center, hme_state, sh, hme_lds);
 }
 
+#ifdef SVTHIP_HME_STAMPS
+// debug build only (tools/hme_stamps_probe.py): copy the phase stamps of the last launches to the host
+extern "C" int svthip_debug_hme_stamps(void* host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hme_stamps), bytes < sizeof(g_hme_stamps) ? bytes : sizeof(g_hme_stamps));
+}
+#endif
+
 }  // namespace svthip

@@ -37,6 +37,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
+// Optional per-phase time stamps (tools/hme_stamps_probe.py builds a copy of the library with -DSVTHIP_HME_STAMPS): s_memtime of lane 0 of
+// every region wave at the phase boundaries of hme_center_sb, [superblock][wave][8].
+#ifdef SVTHIP_HME_STAMPS
+__device__ unsigned long long g_hme_stamps[8192 * 4 * 8];
+#define HME_STAMP(i)                                                                                                          \
+    do {                                                                                                                      \
+        if (lane == 0 && sbi < 8192u) g_hme_stamps[((size_t)sbi * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HME_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
 #pragma unroll
@@ -468,6 +480,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
     const uint8_t* cur_full = pool + cur.full_offset + (size_t)68 * cur.full_stride + 68;
     const uint8_t* ref_full = pool + ref.full_offset + (size_t)68 * ref.full_stride + 68;
     const uint8_t* src = cur_full + (size_t)oy * cur.full_stride + ox;
+    HME_STAMP(0);
 
     // full 64x64 SBs: stage the three source blocks once for the whole workgroup (the four region waves search with the same
     // block at every level, and the centre checks compare the same 64 x 32-row block)
@@ -489,6 +502,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
         __syncthreads();
     }
     const uint32_t* src2_lds = full_sb ? sh.src2 : nullptr;
+    HME_STAMP(1);
 
     const bool center_path = (P.temporal_layer_index > 0) || (list_index == 0);  // :6300
     const uint32_t mv64 = (list_index == 1 && l0_best_mv64) ? l0_best_mv64[(size_t)sbi * l0_mv_stride] : 0u;
@@ -536,6 +550,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                 int x0 = xc, y0 = yc, x1 = xc, y1 = yc, x2 = xc, y2 = yc;
                 if (carried) { x0 = st[k]; y0 = st[4 + k]; x1 = st[8 + k]; y1 = st[12 + k]; x2 = st[16 + k]; y2 = st[20 + k]; }
                 uint32_t sad0 = 0, sad1 = 0, sad2 = 0;
+                HME_STAMP(2);
                 if (P.enable_hme_level0_flag) {  // HmeLevel0 :4306-4503, 1/16 picture
                     const uint32_t mx = P.hme_level0_multiplier_x, my = P.hme_level0_multiplier_y;
                     int sw = s16((int)((P.hme_level0_search_area_in_width_array[rw] * mx) / 100));
@@ -559,6 +574,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     x0 = s16(s16(bx + xo) * 4);
                     y0 = s16(s16(by + yo) * 4);
                 }
+                HME_STAMP(3);
                 if (P.enable_hme_level1_flag) {  // HmeLevel1 :4505-4625, 1/4 picture
                     int sw = round_hme_width((int)(int16_t)P.hme_level1_search_area_in_width_array[rw]);
                     int shh = (int)(int16_t)P.hme_level1_search_area_in_height_array[rh];
@@ -577,6 +593,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     x1 = s16(s16(bx + xo) * 2);
                     y1 = s16(s16(by + yo) * 2);
                 }
+                HME_STAMP(4);
                 if (P.enable_hme_level2_flag) {  // HmeLevel2 :4627-4758, full resolution
                     int sw = round_hme_width((int)(int16_t)P.hme_level2_search_area_in_width_array[rw]);
                     int shh = (int)(int16_t)P.hme_level2_search_area_in_height_array[rh];
@@ -593,6 +610,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     x2 = s16(bx + xo);
                     y2 = s16(by + yo);
                 }
+                HME_STAMP(5);
                 if (lane == 0) {
                     sh.rx[0][k] = x0; sh.ry[0][k] = y0; sh.rs[0][k] = (unsigned long long)sad0 * 2;
                     sh.rx[1][k] = x1; sh.ry[1][k] = y1; sh.rs[1][k] = (unsigned long long)sad1 * 2;
@@ -676,6 +694,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
         if (m == z) { xc = 0; yc = 0; }
     }
 
+    HME_STAMP(6);
     if (tid == 0) {
         int sw = min((int)P.search_area_width, 127), shh = min((int)P.search_area_height, 127);
         int xo = s16(xc - (sw >> 1)), yo = s16(yc - (shh >> 1));
