@@ -155,6 +155,13 @@ __device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, c
     *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
 }
 
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS (row r at
@@ -393,6 +400,19 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
             // 16 keys: (sad << 16) + raster index; positions beyond the search width and padding lanes never win
             const int xs0 = 16 * io;
             const uint32_t base = (uint32_t)((y0 + iy) * sw + xs0);
+            if ((sw & 15) == 0) {
+                // every item is 16 valid positions (wave-uniform case; the reference's default areas): one v_lshl_or / v_and_or per key and
+                // one v_min3 per two keys instead of compare + select + add + min per position; only the padding lanes are masked, once
+                uint32_t lb = 0xffffffffu;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t lo = (uint32_t)acc[g], hi = (uint32_t)(acc[g] >> 32), ix = base + 4u * (uint32_t)g;
+                    lb = min3u((lo << 16) | ix, (lo & 0xffff0000u) | (ix + 1u), lb);
+                    lb = min3u((hi << 16) | (ix + 2u), (hi & 0xffff0000u) | (ix + 3u), lb);
+                }
+                best = min(best, valid ? lb : 0xffffffffu);
+                continue;
+            }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 const uint32_t lo = (uint32_t)acc[g], hi = (uint32_t)(acc[g] >> 32);
