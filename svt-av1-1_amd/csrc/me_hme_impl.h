@@ -164,60 +164,42 @@ __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
 
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS (row r at
-// win + r * pitch).  Lane = (row group, dword column): a lane keeps its column and walks down the rows, 8 rows in flight, so
-// the per-dword cost is two address adds, the aligned-pair loads, one v_alignbyte and the LDS store.  Reads up to
-// pitch * 4 + 7 bytes per row.
+// Copies `wrows` plane rows of `pitch` dwords each, starting at the (unaligned) address `base`, into LDS (row r at win + r * pitch).
+// Reads up to pitch * 4 + 19 bytes per row (the pool's tail slack covers the last row of the last plane).  pitch <= 256 (a band of at
+// least 15 rows has to fit the 8 KB slice, so pitch <= 136 here).
 __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t ref_stride_raw, int wrows, int pitch, uint32_t* win,
                                                   int lane)
 {
-    if (pitch <= 64) {
-        const int cshift = pitch <= 16 ? 4 : (pitch <= 32 ? 5 : 6);
-        const int G = 64 >> cshift;                        // rows per wave pass
-        const int g = lane >> cshift;
-        const int c = min(lane & ((1 << cshift) - 1), pitch - 1);
-        const bool col_ok = (lane & ((1 << cshift) - 1)) < pitch;
-        const uint8_t* p = base + (size_t)g * ref_stride_raw + 4u * (uint32_t)c;
-        uint32_t* w = win + g * pitch + c;
-        const size_t step = (size_t)G * ref_stride_raw;    // uniform
-        const int wstep = G * pitch;
-        int r = g;
-        for (; r + 7 * G < wrows; r += 8 * G) {            // all 8 rows of this lane exist
-            uint32_t v[8];
+    // A lane moves FOUR consecutive dwords of a row: five aligned dwords in (16 + 4 bytes), four v_alignbyte, four LDS stores -- about
+    // 2.5 VALU instructions per dword against 7 for the one-dword-per-lane copy this replaces (levels 1 / 2 stage 13 / 19 dwords per
+    // row, which filled 13 of 16 / 19 of 32 lanes).  lpr lanes per row, rpp rows per wave pass, two passes in flight.
+    const int lpr = (pitch + 3) >> 2;
+    const int rpp = lpr < 64 ? 64 / lpr : 1;
+    const int g = (int)(((uint32_t)lane * ((1u << 16) / (uint32_t)lpr + 1u)) >> 16), q4 = 4 * (lane - g * lpr);
+    const bool lane_ok = g < rpp;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(base) + 4u * (uint32_t)q4;
+    for (int r0 = g; r0 < wrows; r0 += 2 * rpp) {
+        uint32_t w[2][5];
+        uint32_t sh[2];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = ldu32_nb(p + (size_t)k * step);
-            if (col_ok) {
+        for (int u = 0; u < 2; u++) {
+            const int r = min(r0 + u * rpp, wrows - 1);  // clamped: the loads stay unconditional and in flight together
+            const uintptr_t a = a0 + (size_t)r * ref_stride_raw;
+            gmem_u32* q = (gmem_u32*)(a & ~(uintptr_t)3);
+            sh[u] = (uint32_t)(a & 3u);
 #pragma unroll
-                for (int k = 0; k < 8; k++) w[k * wstep] = v[k];
+            for (int k = 0; k < 5; k++) w[u][k] = q[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int r = r0 + u * rpp;
+            if (lane_ok && r < wrows) {
+                uint32_t* o = win + r * pitch + q4;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (q4 + k < pitch) o[k] = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], sh[u]);
             }
-            p += 8 * step;
-            w += 8 * wstep;
         }
-        {                                                   // tail: rows clamped for the loads, masked for the stores
-            uint32_t v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int rr = min(r + k * G, wrows - 1) - r;   // >= 0 whenever this lane stores anything
-                v[k] = ldu32_nb(p + (ptrdiff_t)(rr * (int)ref_stride_raw));  // |rr| < 2^10, stride < 2^16: a 32-bit product
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (col_ok && r + k * G < wrows) w[k * wstep] = v[k];
-        }
-        return;
-    }
-    const int total = wrows * pitch;
-    const uint32_t inv_pitch = (1u << 20) / (uint32_t)pitch + 1u;  // i / pitch == (i * inv) >> 20 for i < 2^20 / pitch
-    for (int i0 = 0; i0 < total; i0 += 512) {
-        uint32_t v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = min(i0 + k * 64 + lane, total - 1);  // clamped, branch-free
-            const int r = (int)(((uint32_t)i * inv_pitch) >> 20), c = i - r * pitch;
-            v[k] = ldu32_nb(base + (uint32_t)r * ref_stride_raw + 4u * (uint32_t)c);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) win[min(i0 + k * 64 + lane, total - 1)] = v[k];
     }
 }
 
