@@ -214,7 +214,9 @@ __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t 
 // `lds` is this wave's private slice of `lds_bytes` bytes; the search area is processed in bands of rows that fit.
 // `shared_src` (may be null): the H x W source block already staged in LDS by the workgroup ([H][W / 4] dwords, shared by the
 // four region waves); then the whole slice holds the window.
-template <int W>
+// KEY32: the caller guarantees sw * sh <= 4096 (the reference's level-1 / level-2 areas are 256 / 64 positions) and every W x H here has
+// SAD < 2^20, so the best position is a 32-bit minimum of sad << 12 | position instead of a 64-bit one.
+template <int W, bool KEY32 = false>
 __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride_raw,
                                   int H, int sw, int sh, int lane, uint8_t* lds, int lds_bytes, uint32_t* best_sad,
                                   int* bx, int* by, const uint32_t* shared_src = nullptr)
@@ -251,6 +253,7 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     // items and row-parts
     const int items_row = noct;
     unsigned long long best = ~0ull;
+    uint32_t best32 = 0xffffffffu;
 
     for (int y0 = 0; y0 < sh; y0 += band) {
         const int bh = min(band, sh - y0);
@@ -311,15 +314,25 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
                 for (int j = 0; j < 8; j++) {
                     const int xs = 8 * io + j;
                     if (xs < sw) {
-                        const unsigned long long key = ((unsigned long long)sad[j] << 32) | (uint32_t)(ys * sw + xs);
-                        best = key < best ? key : best;  // raster order within the lane: strict '<' keeps the first
+                        if (KEY32) {
+                            best32 = min(best32, (sad[j] << 12) | (uint32_t)(ys * sw + xs));
+                        } else {
+                            const unsigned long long key = ((unsigned long long)sad[j] << 32) | (uint32_t)(ys * sw + xs);
+                            best = key < best ? key : best;  // raster order within the lane: strict '<' keeps the first
+                        }
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    best = wave_min_u64(best);
+    if (KEY32) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) best32 = min(best32, (uint32_t)__shfl_xor((int)best32, m));
+        best = ((unsigned long long)(best32 >> 12) << 32) | (best32 & 0xfffu);
+    } else {
+        best = wave_min_u64(best);
+    }
     const uint32_t pos = (uint32_t)best;
     *best_sad = (uint32_t)(best >> 32);
     *by = (int)(pos / (uint32_t)sw);
@@ -586,7 +599,10 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     const uint8_t* s = pool + cur.quarter_offset + (size_t)(32 + o_y) * cur.quarter_stride + 32 + o_x;
                     const uint8_t* r = pool + ref.quarter_offset + (size_t)(32 + o_y + yo) * ref.quarter_stride + 32 + o_x + xo;
                     int bx, by;
-                    if (sb_w == 64)
+                    if (sb_w == 64 && sw * shh <= 4096)
+                        wave_sad_loop_lds<32, true>(s, cur.quarter_stride * 2, r, ref.quarter_stride, 16, sw, shh, lane, wlds,
+                                                    kHmeLdsPerWave, &sad1, &bx, &by, sh.src1);
+                    else if (sb_w == 64)
                         wave_sad_loop_lds<32>(s, cur.quarter_stride * 2, r, ref.quarter_stride, 16, sw, shh, lane, wlds,
                                               kHmeLdsPerWave, &sad1, &bx, &by, sh.src1);
                     else
@@ -603,7 +619,10 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
                     clip_window(xo, yo, sw, shh, ox, oy, 63, 63, ref.width, ref.height);
                     const uint8_t* r = ref_full + (size_t)(oy + yo) * ref.full_stride + ox + xo;
                     int bx, by;
-                    if (sb_w == 64)
+                    if (sb_w == 64 && sw * shh <= 4096)
+                        wave_sad_loop_lds<64, true>(src, cur.full_stride * 2, r, ref.full_stride, 32, sw, shh, lane, wlds,
+                                                    kHmeLdsPerWave, &sad2, &bx, &by, sh.src2);
+                    else if (sb_w == 64)
                         wave_sad_loop_lds<64>(src, cur.full_stride * 2, r, ref.full_stride, 32, sw, shh, lane, wlds,
                                               kHmeLdsPerWave, &sad2, &bx, &by, sh.src2);
                     else
