@@ -263,13 +263,13 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
         const int nitems = items_row * bh;
-        int RP = 1;
-        while (RP < 8 && nitems * RP * 2 <= 64 && RP * 2 <= H) RP <<= 1;
-        const int ipw = 64 / RP;              // items per wave pass
+        int RP = 1, rp_shift = 0;
+        while (RP < 8 && nitems * RP * 2 <= 64 && RP * 2 <= H) { RP <<= 1; rp_shift++; }
+        const int ipw = 64 >> rp_shift;       // items per wave pass
         const int part = lane & (RP - 1);
         const uint32_t inv_items = (1u << 20) / (uint32_t)items_row + 1u;
         for (int it0 = 0; it0 < nitems; it0 += ipw) {
-            const int item = it0 + (lane / RP);
+            const int item = it0 + (lane >> rp_shift);  // RP is a power of two: no per-lane integer division
             const bool valid = item < nitems;
             const int iy = valid ? (int)(((uint32_t)item * inv_items) >> 20) : 0;
             const int io = valid ? item - iy * items_row : 0;
