@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include "me_kernels.h"
+#include "me_wave_reduce.h"
 
 namespace svthip {
 

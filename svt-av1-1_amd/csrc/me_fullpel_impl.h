@@ -259,28 +259,21 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
     uint32_t* osad = out_sad + (size_t)85 * sbi;
     uint32_t* omv = out_mv + (size_t)85 * sbi;
 
-    uint32_t red[21];
-#pragma unroll
-    for (int i = 0; i < 16; i++) red[i] = wave_min_u32(best8[i]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) red[16 + i] = wave_min_u32(best16[i]);
-    red[20] = wave_min_u32(best32);
+    // the 21 trackers of this quadrant in two reduce-scatter passes (me_wave_reduce.h): lanes 0..15 end up with the 8x8 PUs,
+    // lanes 16..20 with the four 16x16 and the 32x32, and every one of those lanes stores its own PU
+    const uint32_t g8 = wave_min_scatter<16>(best8, lane);
+    const uint32_t top[8] = {best16[0], best16[1], best16[2], best16[3], best32, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    const uint32_t g16 = wave_min_scatter<8, 5>(top, lane);
     const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
 
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 21; i++) {
-            const uint32_t key = red[i];
-            uint32_t raw, id;
-            int pu;
-            if (i < 16) { raw = key >> 16; id = key & 0x3fffu; pu = 21 + 16 * Q + i; }
-            else if (i < 20) { raw = key >> 16; id = key & 0x3fffu; pu = 5 + 4 * Q + (i - 16); }
-            else { raw = key >> 14; id = key & 0x3fffu; pu = 1 + Q; }
-            osad[pu] = 2u * raw;
-            omv[pu] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
-        }
-        atomicMin(best64_lds, k64);
+    if (lane < 21) {
+        const uint32_t key = lane < 16 ? g8 : g16;
+        const int pu = lane < 16 ? 21 + 16 * Q + lane : lane < 20 ? 5 + 4 * Q + (lane - 16) : 1 + Q;
+        const uint32_t raw = lane == 20 ? key >> 14 : key >> 16, id = key & 0x3fffu;
+        osad[pu] = 2u * raw;
+        omv[pu] = mv_word(xo + (int)(id & 127u), yo + (int)(id >> 7));
     }
+    if (lane == 0) atomicMin(best64_lds, k64);
     __syncthreads();
     if (tid == 0) {
         const unsigned long long k = *best64_lds;
