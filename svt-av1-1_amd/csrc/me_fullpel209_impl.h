@@ -67,7 +67,41 @@ __device__ __forceinline__ uint32_t mv_word(int x, int y)
 }
 
 
-constexpr int kFp209Fixed = 16384 + 8192 + 1024;  // exchange buffer, (64x32[1], 32x16[5]) pairs, 64x64 result + best key per PU
+constexpr int kFp209Fixed = 16384 + 8192 + 1280;  // exchange buffer, (64x32[1], 32x16[5]) pairs, 64x64 result + best keys
+
+// Best keys live in LDS in the order the waves produce them (one ds_min_u32 of 64 lanes per group of trackers, see
+// me_wave_reduce.h), not in ME-buffer order:
+//   [16 * (4Q + zz) + j]  the 16x16 block zz of quadrant Q: j = 0..3 its 8x8, 4 the 16x16, 5,6 16x8, 7,8 8x16, then the 32x8 pair
+//                         (right-hand blocks) and / or the 8x32 pair (lower blocks) that end in this block
+//   [256 + 8Q + j]        quadrant Q: j = 0 the 32x32, 1,2 32x16, 3,4 16x32
+//   [288 + j]             across quadrants: j = 0,1 64x32, 2,3 32x64, 4..7 64x16, 8..11 16x64
+constexpr int kFp209Slots = 304;
+constexpr int fp209_slot_of_pu(int pu)
+{
+    if (pu >= 205) return 288 + 8 + (pu - 205);
+    if (pu >= 201) return 288 + 4 + (pu - 201);
+    if (pu >= 185) { const int t = pu - 185, Q = t >> 2, C = (t >> 1) & 1; return 16 * (4 * Q + 2 + C) + (C ? 11 : 9) + (t & 1); }
+    if (pu >= 169) { const int t = pu - 169, Q = t >> 2, R = (t >> 1) & 1; return 16 * (4 * Q + 2 * R + 1) + 9 + (t & 1); }
+    if (pu >= 137) { const int t = pu - 137; return 16 * (t >> 1) + 7 + (t & 1); }
+    if (pu >= 129) { const int t = pu - 129; return 256 + 8 * (t >> 1) + 3 + (t & 1); }
+    if (pu >= 127) return 288 + 2 + (pu - 127);
+    if (pu >= 95) { const int t = pu - 95; return 16 * (t >> 1) + 5 + (t & 1); }
+    if (pu >= 87) { const int t = pu - 87; return 256 + 8 * (t >> 1) + 1 + (t & 1); }
+    if (pu >= 85) return 288 + (pu - 85);
+    if (pu >= 21) { const int t = pu - 21; return 16 * (t >> 2) + (t & 3); }
+    if (pu >= 5) return 16 * (pu - 5) + 4;
+    return pu >= 1 ? 256 + 8 * (pu - 1) : 0;  // PU 0 (64x64) has its own 64-bit cell
+}
+struct Fp209SlotTable {
+    uint16_t v[209];
+};
+constexpr Fp209SlotTable fp209_make_slot_table()
+{
+    Fp209SlotTable t{};
+    for (int pu = 0; pu < 209; pu++) t.v[pu] = (uint16_t)fp209_slot_of_pu(pu);
+    return t;
+}
+__device__ const Fp209SlotTable kFp209SlotOfPu = fp209_make_slot_table();
 
 // d: the superblock's descriptor (6 int32: src_offset, ref_offset, x/y search origin, search width/height), any address space;
 // smem: kFp209Fixed + (sh + 63) * SVTHIP_FULLPEL_LDS_PITCH bytes of workgroup LDS, 16-byte aligned.
@@ -77,15 +111,15 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                                              uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv, uint8_t* smem)
 {
     // LDS layout: [0,16K) exchange buffer, [16K,24K) per-position 64x32[1] / 32x16[5] SADs of the current iteration,
-    // [24K,24K+1K) 64x64 result and one best key per PU, then the window.
+    // [24K,24K+1280) 64x64 result and the best keys, then the window.
     uint32_t* xch = reinterpret_cast<uint32_t*>(smem);
     uint32_t* qa = reinterpret_cast<uint32_t*>(smem + 16384);          // [64 lanes][16 positions] 64x32[1]
     uint32_t* qv = reinterpret_cast<uint32_t*>(smem + 16384 + 4096);   // [64 lanes][16 positions] 32x16[5]
     unsigned long long* best64_lds = reinterpret_cast<unsigned long long*>(smem + 24576);
-    // best (sad << k | raster idx) key of every PU.  Per-lane trackers are reduced over the wave and merged here with
-    // ds_min_u32 as soon as an iteration has produced them: kept in registers across the whole loop (as in the 85-PU kernel) the
-    // 61 trackers of this mode pushed the kernel to 256 VGPRs + scratch spills, which made it 3x slower than the extra VALU work
-    uint32_t* pu_key = reinterpret_cast<uint32_t*>(smem + 24576 + 16);  // [209]
+    // best (sad << k | raster idx) key of every PU (slot order above).  Per-lane trackers are reduced over the wave and merged here
+    // with ds_min_u32 as soon as an iteration has produced them: kept in registers across the whole loop (as in the 85-PU kernel)
+    // the 61 trackers of this mode pushed the kernel to 256 VGPRs + scratch spills, which made it 3x slower than the extra VALU work
+    uint32_t* pu_key = reinterpret_cast<uint32_t*>(smem + 24576 + 16);  // [kFp209Slots]
     uint8_t* win = smem + kFp209Fixed;
 
     const int tid = threadIdx.x;
@@ -123,7 +157,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             reinterpret_cast<uint32_t*>(win)[i] = v;
         }
         if (tid == 0) *best64_lds = ~0ull;
-        if (tid < 209) pu_key[tid] = 0xffffffffu;
+        for (int i = tid; i < kFp209Slots; i += 256) pu_key[i] = 0xffffffffu;
     }
     __syncthreads();
 
@@ -135,22 +169,10 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     uint32_t q5_raw = 0xffffffffu, q5_idx = 0;  // PU 32x16[5]: wave-uniform state of the recurrence (wave 0 only)
 
     const uint32_t himask = 0xffff0000u;
-    // LDS minimum without return value.  atomicMin() would do, but its lowering wraps every call in a "first active lane"
-    // sequence (v_mbcnt + branch) although the call already sits in a lane-0 block: 60 extra branches per iteration.
-    auto lds_min = [&](uint32_t* p, uint32_t v) {
-        const uint32_t off = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)p);
-        asm volatile("ds_min_u32 %0, %1" ::"v"(off), "v"(v) : "memory");
-    };
-    // wave-wide minimum as a scalar: four fused DPP min steps leave every row of 16 lanes with its minimum, four v_readlane +
-    // scalar min combine the rows: 8 VALU instructions, no LDS round trips (61 reductions per iteration)
-    auto wmin = [&](uint32_t key) -> uint32_t {
-        asm("v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(key));
-        asm("v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(key));
-        asm("v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(key));
-        asm("v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(key));
-        return min(min((uint32_t)__builtin_amdgcn_readlane((int)key, 0), (uint32_t)__builtin_amdgcn_readlane((int)key, 16)),
-                   min((uint32_t)__builtin_amdgcn_readlane((int)key, 32), (uint32_t)__builtin_amdgcn_readlane((int)key, 48)));
-    };
+    // A group of up to 16 trackers goes through row_min_scatter (lane l: tracker l & 15 reduced over its row of 16) and then
+    // one ds_min_u32 in which the four rows meet in the tracker's LDS slot: about 3 VALU instructions per tracker instead of 8,
+    // and one LDS instruction per group instead of one per tracker.
+    const uint32_t key_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t*)pu_key);
     const int n_items = n_xg * sh;
     const int n_iter = (n_items + 63) >> 6;
 
@@ -163,6 +185,14 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 
         // per-position raster index; positions outside the search area get idx = ~0 so that every key
         // OR-ed with it is 0xffffffff and can never win (at least one position is always valid)
+        // per-lane slot addresses of the tracker groups (byte addresses in LDS; the group offset goes into the instruction).
+        // Formed inside the loop from an opaque copy of the lane number: hoisted out of the loop they would sit in VGPRs that the
+        // kernel does not have (it runs at the 168-register limit of three workgroups per CU)
+        uint32_t lane_v = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_v));
+        const uint32_t slot16 = key_lds + 4 * (lane_v & 15);        // + 4 * (64Q + 16zz) or + 4 * 288
+        const uint32_t slot8 = key_lds + 4 * (lane_v & 7) + 32 * Q;  // + 4 * 256
+
         uint32_t idx[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -238,6 +268,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
+            const uint32_t c0 = quad_min_scatter<4>(k8[0], k8[1], k8[2], k8[3], lane);  // first part of the group reduction below
 
             // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
 #pragma unroll
@@ -278,21 +309,27 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                                               &idx[4 * q], himask);
                 }
             }
-            // publish this 16x16's trackers (ME-buffer indices: z16 = 4Q + zz): reduce first, then one lane-0 block of ds_min
-            const int z16 = 4 * Q + zz;
-            const uint32_t m8[4] = {wmin(k8[0]), wmin(k8[1]), wmin(k8[2]), wmin(k8[3])};
-            const uint32_t m16 = wmin(k16), mt = wmin(k16x8[0]), mb = wmin(k16x8[1]), ml = wmin(k8x16[0]), mr = wmin(k8x16[1]);
-            uint32_t mw0 = 0, mw1 = 0, mh0 = 0, mh1 = 0;
-            if (C == 1) { mw0 = wmin(k32x8[0]); mw1 = wmin(k32x8[1]); }
-            if (R == 1) { mh0 = wmin(k8x32[0]); mh1 = wmin(k8x32[1]); }
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) lds_min(&pu_key[21 + 4 * z16 + k], m8[k]);
-                lds_min(&pu_key[5 + z16], m16);
-                lds_min(&pu_key[95 + 2 * z16], mt); lds_min(&pu_key[95 + 2 * z16 + 1], mb);
-                lds_min(&pu_key[137 + 2 * z16], ml); lds_min(&pu_key[137 + 2 * z16 + 1], mr);
-                if (C == 1) { lds_min(&pu_key[169 + 4 * Q + 2 * R], mw0); lds_min(&pu_key[169 + 4 * Q + 2 * R + 1], mw1); }
-                if (R == 1) { lds_min(&pu_key[185 + 4 * Q + 2 * C], mh0); lds_min(&pu_key[185 + 4 * Q + 2 * C + 1], mh1); }
+            // publish this 16x16's trackers into slots 16 * (4Q + zz) + j
+            {
+                constexpr uint32_t NONE = 0xffffffffu;
+                const uint32_t c1 = quad_min_scatter<4>(k16, k16x8[0], k16x8[1], k8x16[0], lane);
+                uint32_t r;
+                if (C == 1 && R == 1) {
+                    const uint32_t c2 = quad_min_scatter<4>(k8x16[1], k32x8[0], k32x8[1], k8x32[0], lane);
+                    const uint32_t c3 = quad_min_scatter<1>(k8x32[1], NONE, NONE, NONE, lane);
+                    r = row_min_from_quads<4>(c0, c1, c2, c3, lane);
+                } else if (C == 1 || R == 1) {
+                    const uint32_t c2 = quad_min_scatter<3>(k8x16[1], C == 1 ? k32x8[0] : k8x32[0], C == 1 ? k32x8[1] : k8x32[1], NONE, lane);
+                    r = row_min_from_quads<3>(c0, c1, c2, NONE, lane);
+                } else {
+                    const uint32_t c2 = quad_min_scatter<1>(k8x16[1], NONE, NONE, NONE, lane);
+                    r = row_min_from_quads<3>(c0, c1, c2, NONE, lane);
+                }
+                const uint32_t a = slot16 + 256 * Q;
+                if (zz == 0) ds_min_u32_off<0>(a, r);
+                else if (zz == 1) ds_min_u32_off<64>(a, r);
+                else if (zz == 2) ds_min_u32_off<128>(a, r);
+                else ds_min_u32_off<192>(a, r);
             }
         }
         // 32x16 (top / bottom) and 16x32 (left / right) of the quadrant: packed sums of two 16x16 (<= 65280 still fits 16 bits)
@@ -333,13 +370,9 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         }
 
         {
-            const uint32_t m32 = wmin(k32), ma = wmin(k32x16[0]), mb = wmin(k32x16[1]), mc = wmin(k16x32[0]), md = wmin(k16x32[1]);
-            if (lane == 0) {
-                lds_min(&pu_key[1 + Q], m32);
-                lds_min(&pu_key[87 + 2 * Q], ma);
-                if (Q != 2) lds_min(&pu_key[87 + 2 * Q + 1], mb);  // PU 92 (32x16[5]) follows the recurrence
-                lds_min(&pu_key[129 + 2 * Q], mc); lds_min(&pu_key[129 + 2 * Q + 1], md);
-            }
+            // PU 92 (32x16[5], Q == 2) follows the recurrence instead: its tracker was never updated and stays 0xffffffff
+            const uint32_t g[8] = {k32, k32x16[0], k32x16[1], k16x32[0], k16x32[1], 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            ds_min_u32_off<4 * 256>(slot8, row_min_scatter<8, 5>(g, lane));
         }
 
         // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
@@ -355,13 +388,13 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         uint32_t cidx[4];  // idx of positions 4Q..4Q+3 (idx[] is indexed statically, so rebuilt from Q)
 #pragma unroll
         for (int j = 0; j < 4; j++) cidx[j] = (lane_valid && xbase + j < sw) ? ibase + j : 0xffffffffu;
+        uint32_t kc[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, kd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         {
             uint4 v[4];
 #pragma unroll
             for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
             const uint32_t q0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, q1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
             const uint32_t q2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, q3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
-            uint32_t kc[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t top = q0[j] + q1[j], bot = q2[j] + q3[j], lef = q0[j] + q2[j], rig = q1[j] + q3[j], all = top + bot;
@@ -375,8 +408,6 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
                 qa[lane * 16 + 4 * Q + j] = bot;                     // 64x32[1] per position, for the 32x16[5] recurrence
             }
-            const uint32_t mk[4] = {wmin(kc[0]), wmin(kc[1]), wmin(kc[2]), wmin(kc[3])};
-            if (lane == 0) { lds_min(&pu_key[85], mk[0]); lds_min(&pu_key[86], mk[1]); lds_min(&pu_key[127], mk[2]); lds_min(&pu_key[128], mk[3]); }
         }
         // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
         __syncthreads();
@@ -396,7 +427,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         __syncthreads();
         {
             // positions 4Q..4Q+3 = dwords (2Q, 2Q+1) of each PU's 8-dword run: [w][R] at xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q
-            uint32_t pr[4][2][4], kd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            uint32_t pr[4][2][4];
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
@@ -411,8 +442,6 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 kd[2] = min(kd[2], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
                 kd[3] = min(kd[3], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
             }
-            const uint32_t mk[4] = {wmin(kd[0]), wmin(kd[1]), wmin(kd[2]), wmin(kd[3])};
-            if (lane == 0) { lds_min(&pu_key[201], mk[0]); lds_min(&pu_key[202], mk[1]); lds_min(&pu_key[203], mk[2]); lds_min(&pu_key[204], mk[3]); }
         }
         // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
         __syncthreads();
@@ -440,8 +469,10 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 ke[2] = min(ke[2], ((pc[1][0][j] + pc[3][0][j]) << 14) | cidx[j]);  // 16x64[2] = 16x32[2] + 16x32[6]
                 ke[3] = min(ke[3], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
             }
-            const uint32_t mk[4] = {wmin(ke[0]), wmin(ke[1]), wmin(ke[2]), wmin(ke[3])};
-            if (lane == 0) { lds_min(&pu_key[205], mk[0]); lds_min(&pu_key[206], mk[1]); lds_min(&pu_key[207], mk[2]); lds_min(&pu_key[208], mk[3]); }
+            // the twelve cross-quadrant trackers of this wave's positions in one group (slots 288 + j)
+            const uint32_t g[16] = {kc[0], kc[1], kc[2], kc[3], kd[0], kd[1], kd[2], kd[3], ke[0], ke[1], ke[2], ke[3],
+                                    0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            ds_min_u32_off<4 * 288>(slot16, row_min_scatter<16, 12>(g, lane));
         }
         if (Q == 0) {
             // 32x16[5] (:343-347): in raster order, "if (sad of 64x32[1] < best) best = sad of 32x16[5]".  The items of an
@@ -494,7 +525,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         } else {
             // 32x32 and the cross-quadrant rectangles carry raw << 14, everything else raw << 16 (idx = y * 128 + x, 14 bits)
             const bool wide = (pu >= 1 && pu <= 4) || pu == 85 || pu == 86 || pu == 127 || pu == 128 || pu >= 201;
-            const uint32_t key = pu_key[pu];
+            const uint32_t key = pu_key[kFp209SlotOfPu.v[pu]];
             raw = wide ? key >> 14 : key >> 16;
             id = key & 0x3fffu;
         }

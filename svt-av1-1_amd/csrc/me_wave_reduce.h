@@ -54,6 +54,36 @@ template <int N, int NV = N> __device__ __forceinline__ uint32_t row_min_scatter
     }
 }
 
+// The two halves of row_min_scatter<16> for callers whose trackers become final at different times (fewer registers live):
+// quad_min_scatter leaves lane l with tracker (l & 3) of {a, b, c, d} reduced over its quad (the first NV of them real);
+// row_min_from_quads folds four such results (trackers 0..3, 4..7, 8..11, 12..15; the first NQ real) into the row result.
+template <int NV = 4> __device__ __forceinline__ uint32_t quad_min_scatter(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int lane)
+{
+    const uint32_t in[4] = {a, b, c, d};
+    uint32_t r1[2], r2[1];
+    scatter_step<0xB1, 4, NV>(in, r1, lane & 1);
+    scatter_step<0x4E, 2, (NV + 1) / 2>(r1, r2, lane & 2);
+    return r2[0];
+}
+
+template <int NQ = 4> __device__ __forceinline__ uint32_t row_min_from_quads(uint32_t q0, uint32_t q1, uint32_t q2, uint32_t q3, int lane)
+{
+    const uint32_t in[4] = {q0, q1, q2, q3};
+    uint32_t r3[2], r4[1];
+    scatter_step<0x124, 4, NQ>(in, r3, lane & 4);
+    scatter_step<0x128, 2, (NQ + 1) / 2>(r3, r4, lane & 8);
+    return r4[0];
+}
+
+// LDS minimum without return value at byte address addr + OFF (OFF in the instruction's offset field).  atomicMin() would do, but
+// its lowering wraps every call in a "first active lane" sequence; the caller needs an s_waitcnt lgkmcnt(0) before other
+// waves read the cell, the compiler's counter tracking does not see this instruction.
+template <int OFF> __device__ __forceinline__ void ds_min_u32_off(uint32_t addr, uint32_t v)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit offset field");
+    asm volatile("ds_min_u32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
 // the same over the whole wave: every lane l ends up with the minimum of v[l & (N-1)] over all 64 lanes
 template <int N, int NV = N> __device__ __forceinline__ uint32_t wave_min_scatter(const uint32_t (&v)[N], int lane)
 {
