@@ -87,6 +87,16 @@ __global__ void __launch_bounds__(1024) bench(uint32_t* out, uint64_t* cyc, uint
                     asm volatile("v_add_u32 %0, %0, %1" : "+v"(b[i]) : "v"(a[i])); }
                 else if (OP == 33) { /* qsad with SGPR src1 */
                     asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(p[i]) : "v"(q[i]), "s"(s)); }
+                else if (OP == 34) { /* (sad << 16 | idx) key in one SDWA move: the low half of the destination (idx) is kept */
+                    asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(a[i]) : "v"(b[i])); }
+                else if (OP == 35) { asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(a[i]) : "v"(b[i])); }
+                else if (OP == 36) { asm volatile("v_or_b32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i])); }
+                else if (OP == 37) { /* mixed: 1 qsad + 2 SDWA keys + 1 min3 + 1 SDWA key + ... (x5) */
+                    p[i] = __builtin_amdgcn_qsad_pk_u16_u8(q[i], s, p[i]);
+                    asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(a[i]) : "v"(b[i]));
+                    asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(b[i]) : "v"(a[i]));
+                    asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(s));
+                    asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0" : "+v"(b[i]) : "v"(a[i])); }
             }
         }
     }
@@ -150,14 +160,16 @@ int main()
         {"v_lshlrev_b64", bench<24>}, {"v_min_u16", bench<25>}, {"v_pk_sub_u16", bench<26>},
         {"v_pk_max_u16", bench<27>}, {"v_pk_sub_i16_clamp", bench<28>}, {"v_sad_u32", bench<29>},
         {"v_dot4_u32_u8", bench<30>}, {"mix qsad+4xVOP3 (x5)", bench<31>}, {"mix qsad+4xadd (x5)", bench<32>},
-        {"v_qsad sgpr src1", bench<33>},
+        {"v_qsad sgpr src1", bench<33>}, {"v_mov_b32_sdwa key lo", bench<34>}, {"v_mov_b32_sdwa key hi", bench<35>},
+        {"v_or_b32_e32", bench<36>}, {"mix qsad+3sdwa+min3 (x5)", bench<37>},
     };
     const int ninstr = ITER * 32;
     if (getenv("UB_BLOCKS")) {
         // occupancy built from k independent 256-thread workgroups per CU (the ME kernels' shape) instead of one large workgroup
         printf("%-22s   per-wave cycles per instruction (median) at k = 1..6 workgroups of 256 threads per CU; (SIMD rate = value / k)\n", "instr");
         for (auto& e : tab) {
-            if (!(strstr(e.name, "sad") || strstr(e.name, "mix") || strstr(e.name, "v_add_u32") || strstr(e.name, "v_min3"))) continue;
+            if (!(strstr(e.name, "sad") || strstr(e.name, "mix") || strstr(e.name, "v_add_u32") || strstr(e.name, "v_min3") || strstr(e.name, "sdwa") || strstr(e.name, "v_or") ||
+                  strstr(e.name, "v_lshl_or"))) continue;
             printf("%-22s", e.name);
             for (int k = 1; k <= 6; k++) {
                 const int blocks = nblk * k;
