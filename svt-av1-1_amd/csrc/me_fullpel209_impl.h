@@ -113,8 +113,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     // LDS layout: [0,16K) exchange buffer, [16K,24K) per-position 64x32[1] / 32x16[5] SADs of the current iteration,
     // [24K,24K+1280) 64x64 result and the best keys, then the window.
     uint32_t* xch = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* qa = reinterpret_cast<uint32_t*>(smem + 16384);          // [64 lanes][16 positions] 64x32[1]
-    uint32_t* qv = reinterpret_cast<uint32_t*>(smem + 16384 + 4096);   // [64 lanes][16 positions] 32x16[5]
+    uint32_t* qa = reinterpret_cast<uint32_t*>(smem + 16384);          // [4 position quads][64 lanes][4] 64x32[1]
+    uint32_t* qv = reinterpret_cast<uint32_t*>(smem + 16384 + 4096);   // [4 position quads][64 lanes][4] 32x16[5]
     unsigned long long* best64_lds = reinterpret_cast<unsigned long long*>(smem + 24576);
     // best (sad << k | raster idx) key of every PU (slot order above).  Per-lane trackers are reduced over the wave and merged here
     // with ds_min_u32 as soon as an iteration has produced them: kept in registers across the whole loop (as in the 85-PU kernel)
@@ -378,9 +378,11 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
         __syncthreads();  // previous iteration's readers are done
         {
-            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            // exchange layout [wave][uint4 index][lane][4]: 128-bit accesses of consecutive lanes are conflict-free (lane-major rows of
+            // 16 dwords put every second lane on the same banks)
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
 #pragma unroll
-            for (int q = 0; q < 4; q++) dst[q] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
+            for (int q = 0; q < 4; q++) dst[q * 64] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
         }
         __syncthreads();
         const int xbase = 16 * xg + 4 * Q;
@@ -392,9 +394,10 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         {
             uint4 v[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
+            for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + w * 1024 + Q * 256 + lane * 4);
             const uint32_t q0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, q1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
             const uint32_t q2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, q3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+            uint32_t qbot[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t top = q0[j] + q1[j], bot = q2[j] + q3[j], lef = q0[j] + q2[j], rig = q1[j] + q3[j], all = top + bot;
@@ -406,33 +409,34 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 kc[1] = min(kc[1], (bot << 14) | cidx[j]);   // 64x32[1]
                 kc[2] = min(kc[2], (lef << 14) | cidx[j]);   // 32x64[0]
                 kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
-                qa[lane * 16 + 4 * Q + j] = bot;                     // 64x32[1] per position, for the 32x16[5] recurrence
+                qbot[j] = bot;                                       // 64x32[1] per position, for the 32x16[5] recurrence
             }
+            *reinterpret_cast<uint4*>(qa + Q * 256 + lane * 4) = make_uint4(qbot[0], qbot[1], qbot[2], qbot[3]);  // [position quad][lane][4]
         }
         // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
         __syncthreads();
         {
-            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
             dst[0] = make_uint4(r32x16lo[0][0], r32x16hi[0][0], r32x16lo[0][1], r32x16hi[0][1]);
-            dst[1] = make_uint4(r32x16lo[0][2], r32x16hi[0][2], r32x16lo[0][3], r32x16hi[0][3]);
-            dst[2] = make_uint4(r32x16lo[1][0], r32x16hi[1][0], r32x16lo[1][1], r32x16hi[1][1]);
-            dst[3] = make_uint4(r32x16lo[1][2], r32x16hi[1][2], r32x16lo[1][3], r32x16hi[1][3]);
+            dst[64] = make_uint4(r32x16lo[0][2], r32x16hi[0][2], r32x16lo[0][3], r32x16hi[0][3]);
+            dst[128] = make_uint4(r32x16lo[1][0], r32x16hi[1][0], r32x16lo[1][1], r32x16hi[1][1]);
+            dst[192] = make_uint4(r32x16lo[1][2], r32x16hi[1][2], r32x16lo[1][3], r32x16hi[1][3]);
             if (Q == 2) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    *reinterpret_cast<uint4*>(qv + lane * 16 + 4 * q) =
+                    *reinterpret_cast<uint4*>(qv + q * 256 + lane * 4) =
                         make_uint4(r32x16lo[1][q] & 0xffffu, r32x16lo[1][q] >> 16, r32x16hi[1][q] & 0xffffu, r32x16hi[1][q] >> 16);
             }
         }
         __syncthreads();
         {
-            // positions 4Q..4Q+3 = dwords (2Q, 2Q+1) of each PU's 8-dword run: [w][R] at xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q
+            // positions 4Q..4Q+3 = dwords (2Q, 2Q+1) of each PU's 8-dword run, i.e. half (Q & 1) of uint4 2R + (Q >> 1) of wave w
             uint32_t pr[4][2][4];
 #pragma unroll
             for (int w = 0; w < 4; w++)
 #pragma unroll
                 for (int R = 0; R < 2; R++) {
-                    const uint2 t = *reinterpret_cast<const uint2*>(xch + (w * 64 + lane) * 16 + 8 * R + 2 * Q);
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * R + (Q >> 1)) * 256 + lane * 4 + 2 * (Q & 1));
                     pr[w][R][0] = t.x & 0xffffu; pr[w][R][1] = t.x >> 16; pr[w][R][2] = t.y & 0xffffu; pr[w][R][3] = t.y >> 16;
                 }
 #pragma unroll
@@ -446,11 +450,11 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
         __syncthreads();
         {
-            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
             dst[0] = make_uint4(r16x32lo[0][0], r16x32hi[0][0], r16x32lo[0][1], r16x32hi[0][1]);
-            dst[1] = make_uint4(r16x32lo[0][2], r16x32hi[0][2], r16x32lo[0][3], r16x32hi[0][3]);
-            dst[2] = make_uint4(r16x32lo[1][0], r16x32hi[1][0], r16x32lo[1][1], r16x32hi[1][1]);
-            dst[3] = make_uint4(r16x32lo[1][2], r16x32hi[1][2], r16x32lo[1][3], r16x32hi[1][3]);
+            dst[64] = make_uint4(r16x32lo[0][2], r16x32hi[0][2], r16x32lo[0][3], r16x32hi[0][3]);
+            dst[128] = make_uint4(r16x32lo[1][0], r16x32hi[1][0], r16x32lo[1][1], r16x32hi[1][1]);
+            dst[192] = make_uint4(r16x32lo[1][2], r16x32hi[1][2], r16x32lo[1][3], r16x32hi[1][3]);
         }
         __syncthreads();
         {
@@ -459,7 +463,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             for (int w = 0; w < 4; w++)
 #pragma unroll
                 for (int C = 0; C < 2; C++) {
-                    const uint2 t = *reinterpret_cast<const uint2*>(xch + (w * 64 + lane) * 16 + 8 * C + 2 * Q);
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * C + (Q >> 1)) * 256 + lane * 4 + 2 * (Q & 1));
                     pc[w][C][0] = t.x & 0xffffu; pc[w][C][1] = t.x >> 16; pc[w][C][2] = t.y & 0xffffu; pc[w][C][3] = t.y >> 16;
                 }
 #pragma unroll
@@ -481,7 +485,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             uint32_t av[16], vv[16];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint4 a4 = *reinterpret_cast<const uint4*>(qa + lane * 16 + 4 * q), v4 = *reinterpret_cast<const uint4*>(qv + lane * 16 + 4 * q);
+                const uint4 a4 = *reinterpret_cast<const uint4*>(qa + q * 256 + lane * 4), v4 = *reinterpret_cast<const uint4*>(qv + q * 256 + lane * 4);
                 av[4 * q] = a4.x; av[4 * q + 1] = a4.y; av[4 * q + 2] = a4.z; av[4 * q + 3] = a4.w;
                 vv[4 * q] = v4.x; vv[4 * q + 1] = v4.y; vv[4 * q + 2] = v4.z; vv[4 * q + 3] = v4.w;
             }

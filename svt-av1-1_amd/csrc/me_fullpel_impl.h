@@ -229,16 +229,18 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
         // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
         __syncthreads();  // previous iteration's readers are done
         {
-            uint4* dst = reinterpret_cast<uint4*>(xch + (Q * 64 + lane) * 16);
+            // [wave][position quad][lane][4]: a 128-bit access of 8 consecutive lanes covers the 32 banks once (lane-major rows of 16
+            // dwords put every second lane on the same banks: 4-way conflicts on all eight accesses of the exchange)
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
 #pragma unroll
-            for (int q = 0; q < 4; q++) dst[q] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
+            for (int q = 0; q < 4; q++) dst[q * 64] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
         }
         __syncthreads();
         {
             uint4 s = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const uint4 v = *reinterpret_cast<const uint4*>(xch + (w * 64 + lane) * 16 + 4 * Q);
+                const uint4 v = *reinterpret_cast<const uint4*>(xch + w * 1024 + Q * 256 + lane * 4);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
             const uint32_t sv[4] = {s.x, s.y, s.z, s.w};
