@@ -127,12 +127,17 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
         const int xg = pg - y * n_xg;
 
         // per-position raster index; positions outside the search area get idx = ~0 so that every key
-        // OR-ed with it is 0xffffffff and can never win (at least one position is always valid)
+        // OR-ed with it is 0xffffffff and can never win (at least one position is always valid).  A lane past the last item
+        // repeats item 0: its keys duplicate lane 0's of the first pass and change no minimum.  Areas whose width is a multiple
+        // of 16 (the usual case) have no outside positions at all: one add per position instead of compare + select.
         uint32_t idx[16];
+        const uint32_t idx0 = (uint32_t)(y * 128 + 16 * xg);
+        if ((sw & 15) == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int x = 16 * xg + i;
-            idx[i] = (lane_valid && x < sw) ? (uint32_t)(y * 128 + x) : 0xffffffffu;
+            for (int i = 0; i < 16; i++) idx[i] = idx0 + (uint32_t)i;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) idx[i] = (16 * xg + i < sw) ? idx0 + (uint32_t)i : 0xffffffffu;
         }
 
         uint32_t s16lo[4][4], s16hi[4][4];  // [zz][q] packed u16 16x16 sums
