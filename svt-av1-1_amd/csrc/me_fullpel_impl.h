@@ -7,6 +7,10 @@ constexpr int kPitch = SVTHIP_FULLPEL_LDS_PITCH;  // bytes per window row in LDS
 
 __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
+// global loads at byte alignment (one global_load_dword / _dwordx4 each)
+struct __attribute__((packed, aligned(1))) unaligned_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) unaligned_u32x4 { uint32_t v[4]; };
+
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
@@ -80,25 +84,28 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
 
     // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
     {
+        // 16 bytes per thread and pass, read at the window's own byte alignment (global loads need no alignment on this target) and
+        // written as one ds_write_b128: 6 passes for a 64x64 area instead of 24 dword passes with a second load + v_alignbyte each
         const uint8_t* base = ref_plane + ref_off;
-        const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 3u);
-        const uint32_t* base4 = reinterpret_cast<const uint32_t*>(base - a);
         const int rows = sh + 63;
         const int ndw_valid = (sw + 63 + 3) >> 2;
-        const int ndw_row = kPitch >> 2;
-        const int rstride4 = ref_stride >> 2;
-        const int total = rows * ndw_row;
+        constexpr int q_row = kPitch >> 4;
+        const int total = rows * q_row;
         for (int i = tid; i < total; i += 256) {
-            int r = i / ndw_row;
-            int c = i - r * ndw_row;
-            uint32_t v = 0;
-            if (c < ndw_valid) {
-                const uint32_t* p = base4 + (size_t)r * rstride4 + c;
-                uint32_t lo = p[0];
-                uint32_t hi = a ? p[1] : 0u;
-                v = __builtin_amdgcn_alignbyte(hi, lo, a);
+            const int r = i / q_row;
+            const int c4 = i - r * q_row;
+            const uint8_t* p = base + (size_t)r * ref_stride + 16 * c4;
+            const int left = ndw_valid - 4 * c4;  // dwords of this slot that belong to the window
+            uint32_t t[4] = {0u, 0u, 0u, 0u};
+            if (left >= 4) {
+                const unaligned_u32x4 u = *reinterpret_cast<const unaligned_u32x4*>(p);
+                t[0] = u.v[0]; t[1] = u.v[1]; t[2] = u.v[2]; t[3] = u.v[3];
+            } else if (left > 0) {  // the row's last dwords: nothing is read past them
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (k < left) t[k] = reinterpret_cast<const unaligned_u32*>(p + 4 * k)->v;
             }
-            reinterpret_cast<uint32_t*>(win)[i] = v;
+            reinterpret_cast<uint4*>(win)[i] = make_uint4(t[0], t[1], t[2], t[3]);
         }
         if (tid == 0) *best64_lds = ~0ull;
     }
