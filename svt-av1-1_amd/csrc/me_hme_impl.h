@@ -11,6 +11,7 @@
 // integer-to-pointer cast yields a generic pointer and every load becomes a flat_load (which also ties the loads to the LDS
 // counter).  Everything these helpers read lives in the picture pool.
 typedef const __attribute__((address_space(1))) uint32_t gmem_u32;
+struct __attribute__((packed, aligned(1))) gmem_u32x4 { uint32_t v[4]; };  // 16 bytes at byte alignment: one global_load_dwordx4
 
 __device__ __forceinline__ uint32_t ldu32(const uint8_t* p)
 {
@@ -170,25 +171,22 @@ __device__ __forceinline__ uint64_t pack64(uint32_t lo, uint32_t hi) { return ((
 __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t ref_stride_raw, int wrows, int pitch, uint32_t* win,
                                                   int lane)
 {
-    // A lane moves FOUR consecutive dwords of a row: five aligned dwords in (16 + 4 bytes), four v_alignbyte, four LDS stores -- about
-    // 2.5 VALU instructions per dword against 7 for the one-dword-per-lane copy this replaces (levels 1 / 2 stage 13 / 19 dwords per
-    // row, which filled 13 of 16 / 19 of 32 lanes).  lpr lanes per row, rpp rows per wave pass, two passes in flight.
+    // A lane moves FOUR consecutive dwords of a row: one 16-byte global load at the row's own byte alignment (no alignment needed on
+    // this target; round 2 used five aligned dwords + four v_alignbyte) and four LDS stores.  lpr lanes per row, rpp rows per wave
+    // pass, two passes in flight.
     const int lpr = (pitch + 3) >> 2;
     const int rpp = lpr < 64 ? 64 / lpr : 1;
     const int g = (int)(((uint32_t)lane * ((1u << 16) / (uint32_t)lpr + 1u)) >> 16), q4 = 4 * (lane - g * lpr);
     const bool lane_ok = g < rpp;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(base) + 4u * (uint32_t)q4;
     for (int r0 = g; r0 < wrows; r0 += 2 * rpp) {
-        uint32_t w[2][5];
-        uint32_t sh[2];
+        gmem_u32x4 w[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const int r = min(r0 + u * rpp, wrows - 1);  // clamped: the loads stay unconditional and in flight together
-            const uintptr_t a = a0 + (size_t)r * ref_stride_raw;
-            gmem_u32* q = (gmem_u32*)(a & ~(uintptr_t)3);
-            sh[u] = (uint32_t)(a & 3u);
+            const __attribute__((address_space(1))) gmem_u32x4* q = (const __attribute__((address_space(1))) gmem_u32x4*)(a0 + (size_t)r * ref_stride_raw);
 #pragma unroll
-            for (int k = 0; k < 5; k++) w[u][k] = q[k];
+            for (int k = 0; k < 4; k++) w[u].v[k] = q->v[k];
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -197,7 +195,7 @@ __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t 
                 uint32_t* o = win + r * pitch + q4;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if (q4 + k < pitch) o[k] = __builtin_amdgcn_alignbyte(w[u][k + 1], w[u][k], sh[u]);
+                    if (q4 + k < pitch) o[k] = w[u].v[k];
             }
         }
     }
