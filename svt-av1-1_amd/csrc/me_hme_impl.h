@@ -5,8 +5,9 @@
 
 
 // Unaligned 4-byte read as two ALIGNED dword loads + v_alignbyte.  A single misaligned global_load_dword is
-// legal on gfx950 but was measured ~10x slower here (the 64 lanes of a wave are split into per-lane requests);
-// aligned neighbours coalesce into full-rate requests.
+// legal on gfx950; round 1 measured it ~10x slower in the un-staged search loop (the 64 lanes of a wave split into per-lane
+// requests), while for the staging copies (stage_window_rows, the full-pel and sub-pel windows) byte-aligned dword / dwordx4
+// loads turned out as fast as aligned ones and are used there.  The centre check keeps this form (no measurable difference).
 // The aligned address is rebuilt from an integer; the pointer type carries the GLOBAL address space explicitly, otherwise the
 // integer-to-pointer cast yields a generic pointer and every load becomes a flat_load (which also ties the loads to the LDS
 // counter).  Everything these helpers read lives in the picture pool.

@@ -396,22 +396,19 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
             // the dword right of the last needed column may not exist in the plane (only don't-care b samples read it)
             const bool col_ok = cc <= c1 + 1 && 4 * cc < P.PA;
             for (int r0 = rfirst; r0 < nra; r0 += 4 * rstep) {
-                uint32_t lo[4], hi[4], sft[4];
+                // one dword per lane at the window's own byte alignment (global loads need no alignment on this target)
+                struct __attribute__((packed, aligned(1))) u1 { uint32_t v; };
+                uint32_t val[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int rr = r0 + u * rstep;
-                    if (rr < nra && col_ok) {
-                        const uintptr_t a = reinterpret_cast<uintptr_t>(base + (int64_t)(ra0 + rr) * ref_stride + 4 * cc);
-                        const __attribute__((address_space(1))) uint32_t* q = (const __attribute__((address_space(1))) uint32_t*)(a & ~(uintptr_t)3);
-                        lo[u] = q[0];
-                        hi[u] = q[1];
-                        sft[u] = (uint32_t)(a & 3u);
-                    }
+                    if (rr < nra && col_ok)
+                        val[u] = ((const __attribute__((address_space(1))) u1*)reinterpret_cast<uintptr_t>(base + (int64_t)(ra0 + rr) * ref_stride + 4 * cc))->v;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int rr = r0 + u * rstep;
-                    if (rr < nra && col_ok) reinterpret_cast<lds_u32*>(P.A + (ra0 + rr + 3) * P.PA)[cc] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sft[u]);
+                    if (rr < nra && col_ok) reinterpret_cast<lds_u32*>(P.A + (ra0 + rr + 3) * P.PA)[cc] = val[u];
                 }
             }
         }
