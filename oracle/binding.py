@@ -150,6 +150,28 @@ class Oracle:
         f(src_plane.ctypes.data, ss, ref_plane.ctypes.data, rs, desc.ctypes.data, n, int(disable_8x8), sad.ctypes.data, mv.ctypes.data)
         return sad, mv
 
+    def subpel_refine_method(self, src_plane, ref_plane, desc, sad, mv, method, all_pu, disable_8x8=False, src_stride=None,
+                             ref_stride=None):
+        """The refinement under one of the reference's fractional search methods (0 SUB_SAD_SEARCH, 1 FULL_SAD_SEARCH,
+        2 SSD_SEARCH).  In: full-pel (sad, mv) [n, 85 | 209] in ME-buffer order; out: refined copies + half-pel direction [n, npu]."""
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n, npu = desc.shape[0], 209 if all_pu else 85
+        sad = np.ascontiguousarray(sad, dtype=np.uint32).copy()
+        mv = np.ascontiguousarray(mv, dtype=np.uint32).copy()
+        assert sad.shape == (n, npu) and mv.shape == (n, npu)
+        dr = np.zeros((n, npu), np.uint8)
+        f = self.lib.orc_subpel_refine_method
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int16, C.c_int16, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                      C.c_void_p, C.c_void_p]
+        ss = src_stride if src_stride is not None else src_plane.shape[1]
+        rs = ref_stride if ref_stride is not None else ref_plane.shape[1]
+        for i in range(n):
+            d = desc[i]
+            f(src_plane.ctypes.data + int(d[0]), ss, ref_plane.ctypes.data + int(d[1]), rs, int(d[2]), int(d[3]), int(disable_8x8),
+              int(all_pu), int(method), sad[i].ctypes.data, mv[i].ctypes.data, dr[i].ctypes.data)
+        return sad, mv, dr
+
     def bipred_pack_batch(self, src_plane, src_stride, ref0_plane, ref0_stride, desc0, sad0, mv0, ref1_plane=None,
                           ref1_stride=0, desc1=None, sad1=None, mv1=None, bipred_8x8=True, n_pu=85):
         """-> structured array [n,n_pu] of svtav1_hip.ME_CU_RESULT_DTYPE (raster PU order); n_pu = 85 or 209."""
@@ -284,6 +306,43 @@ class Reference:
 
 
 REF_ME_SO = os.path.join(HERE, "_ref", "libsvtref_me.so")
+REF_SUBPEL_SO = os.path.join(HERE, "_ref", "libsvtref_subpel.so")
+
+
+class ReferenceSubpel:
+    """The reference's own HalfPelSearch_LCU + QuarterPelSearch_LCU run with fractionalSearchMethod = SUB_SAD_SEARCH (0) or
+    FULL_SAD_SEARCH (1) (oracle/_ref/libsvtref_subpel.so; oracle/ref_subpel_search_driver.c says why SSD_SEARCH cannot run here)."""
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_SUBPEL_SO)
+
+    def __init__(self):
+        self.lib = C.CDLL(REF_SUBPEL_SO, mode=os.RTLD_LAZY)  # NASM-only symbols stay unresolved by design and are never reached
+        self.lib.ref_subpel_search.restype = C.c_int
+        self.lib.ref_subpel_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def subpel_search(self, src_plane, ref_plane, desc, sad, mv, method, all_pu, disable_8x8=False, asm_type=0):
+        """desc rows as for the oracle: (src_offset, ref_offset, x_origin, y_origin, search_w, search_h); -> (sad, mv, dir)."""
+        desc = np.ascontiguousarray(desc, dtype=np.int32)
+        n, npu = desc.shape[0], 209 if all_pu else 85
+        sad = np.ascontiguousarray(sad, dtype=np.uint32).copy()
+        mv = np.ascontiguousarray(mv, dtype=np.uint32).copy()
+        assert sad.shape == (n, npu) and mv.shape == (n, npu)
+        dr = np.zeros((n, npu), np.uint8)
+        for i in range(n):
+            d = desc[i]
+            # ref_offset points at search position (0,0); the driver wants the sample co-located with the SB origin
+            ref00 = ref_plane.ctypes.data + int(d[1]) - int(d[2]) - int(d[3]) * ref_plane.shape[1]
+            geo = np.array([d[2], d[3], d[4], d[5]], np.int32)
+            rc = self.lib.ref_subpel_search(src_plane.ctypes.data + int(d[0]), src_plane.shape[1], ref00, ref_plane.shape[1],
+                                            geo.ctypes.data, int(method), int(all_pu), int(disable_8x8), int(asm_type),
+                                            sad[i].ctypes.data, mv[i].ctypes.data, dr[i].ctypes.data)
+            if rc != 0:
+                raise RuntimeError(f"ref_subpel_search failed: {rc}")
+        return sad, mv, dr
+
 
 
 class ReferenceME:

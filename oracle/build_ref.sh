@@ -115,6 +115,17 @@ gcc -shared -o "$OUT/libsvtref_me.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_me_lcu_dr
 echo "built $OUT/libsvtref_me.so (unresolved by design: $(nm -D "$OUT/libsvtref_me.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"
 
 # ---------------------------------------------------------------------------------------------
+# libsvtref_subpel.so : the reference's sub-pel refinement (HalfPelSearch_LCU + the static QuarterPelSearch_LCU) run with
+# fractionalSearchMethod = SUB_SAD_SEARCH / FULL_SAD_SEARCH, where Log2f_SSE2 is never evaluated (oracle/ref_subpel_search_driver.c).
+# The driver's translation unit IS the reference's EbMotionEstimation.c (included where it lies, to reach the static function), so it is
+# linked in place of obj_all/EbMotionEstimation.o; everything else as above (same objects, no stand-ins, lazy binding).
+gcc $CFLAGS $INC -std=gnu99 -c "$HERE/ref_subpel_search_driver.c" -o "$OUT/obj/ref_subpel_search_driver.o"
+printf '{ global: ref_subpel_search; local: *; };\n' > "$OUT/obj/subpel.map"
+gcc -shared -o "$OUT/libsvtref_subpel.so" $(ls "$OUT"/obj_all/*.o | grep -v '/EbMotionEstimation\.o$') "$OUT/obj/ref_subpel_search_driver.o" \
+    -Wl,--gc-sections -Wl,--version-script="$OUT/obj/subpel.map" -lm -lpthread
+echo "built $OUT/libsvtref_subpel.so (unresolved by design: $(nm -D "$OUT/libsvtref_subpel.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"
+
+# ---------------------------------------------------------------------------------------------
 # libsvtref_tq.so : the reference's C transform and quantisation entry points (parity targets of the
 # transform/quant kernels): Av1TransformTwoD_NxN_c, av1_fwd_txfm2d_WxH_c, Av1InverseTransformTwoD_NxN_c,
 # av1_inv_txfm2d_add_WxH_c (Codec/EbTransforms.c) and aom_quantize_b*_c_II / aom_highbd_quantize_b*_c

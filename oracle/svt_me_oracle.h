@@ -96,6 +96,10 @@ void orc_pu_geometry209(uint8_t *out);
 void orc_subpel_refine_209pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
                              int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
                              uint32_t *best_mv);
+/* the refinement under any fractional search method (0 SUB_SAD_SEARCH, 1 FULL_SAD_SEARCH, 2 SSD_SEARCH): 85 or 209 PUs, ME-buffer order */
+void orc_subpel_refine_method(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride, int16_t x_search_area_origin,
+                              int16_t y_search_area_origin, int disable_8x8, int all_pu, int method, uint32_t *best_sad, uint32_t *best_mv,
+                              uint8_t *out_dir);
 void orc_subpel_refine209_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
                                 const int32_t *desc, uint32_t n_sb, int disable_8x8, uint32_t *best_sad, uint32_t *best_mv);
 /* orc_bipred_pack_batch over [n_sb][n_pu] arrays, n_pu = 85 or 209 */

@@ -148,32 +148,54 @@ void orc_set_halfpel_dispatch_exact(int on) { g_halfpel_dispatch_exact = on; }
 static const int8_t kHalf[8][5] = {{1, 0, 0, -2, 0}, {1, 1, 0, 2, 0},  {2, 0, 0, 0, -2}, {2, 0, 1, 0, 2},
                                    {3, 0, 0, -2, -2}, {3, 1, 0, 2, -2}, {3, 1, 1, 2, 2},  {3, 0, 1, -2, 2}};
 
-static void pu_half_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo,
+/* MeContext_t::fractionalSearchMethod (Codec/EbDefinitions.h:1846-1848): the distortion the refinement compares.  MotionEstimateLcu
+ * hard-wires SSD_SEARCH (:6254); the two SAD methods run the SAME statements with other leaves and are what the reference itself
+ * can execute in this image (oracle/ref_subpel_search_driver.c), which is how the control flow below is pinned. */
+#define METHOD_SUB_SAD 0  /* 2 x SAD over every second row (strides << 1, height >> 1) */
+#define METHOD_FULL_SAD 1 /* SAD over all rows */
+#define METHOD_SSD 2      /* wrapped 8-bit SSD in the half-pel stage, true SSD in the quarter-pel stage; the stored SAD is the full SAD */
+
+static void pu_half_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo, int method,
                         uint32_t *best_sad, uint32_t *best_mv, uint32_t *best_ssd, uint8_t *dir)
 {
     const int16_t x_mv = (int16_t)(*best_mv & 0xffff), y_mv = (int16_t)(*best_mv >> 16);
     const int xs = (x_mv >> 2) - xo, ys = (y_mv >> 2) - yo;
     const uint8_t *s = src + py * src_stride + px;
     const int hs = g_halfpel_dispatch_exact ? halfpel_ssd_rows(w, h) : h; /* rows the width-keyed SSD leaf covers */
-    uint32_t ssd = 0;
-    for (int y = 0; y < hs; y++)
-        for (int x = 0; x < w; x++) ssd += wrap_sq(s[y * src_stride + x], A_(r, xs + px + x, ys + py + y));
-    *best_ssd = ssd; /* :1912 */
+    if (method == METHOD_SSD) {
+        uint32_t ssd = 0;
+        for (int y = 0; y < hs; y++)
+            for (int x = 0; x < w; x++) ssd += wrap_sq(s[y * src_stride + x], A_(r, xs + px + x, ys + py + y));
+        *best_ssd = ssd; /* :1911-1919 */
+    }
     uint64_t dist[8];
     for (int k = 0; k < 8; k++) {
-        uint32_t d = 0, sad = 0;
+        uint32_t d = 0, sad = 0, sad_even = 0;
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) {
                 const int p = sample(r, kHalf[k][0], xs + px + x + kHalf[k][1], ys + py + y + kHalf[k][2]);
                 const int sv = s[y * src_stride + x];
+                const uint32_t ad = (uint32_t)(sv > p ? sv - p : p - sv);
                 if (y < hs) d += wrap_sq(sv, p);
-                sad += (uint32_t)(sv > p ? sv - p : p - sv);
+                sad += ad;
+                if (!(y & 1)) sad_even += ad;
             }
-        dist[k] = d;
-        if (d < *best_ssd) { /* strict '<', :1942 */
-            *best_sad = sad;  /* true SAD over all rows, :1943 */
-            *best_mv = ((uint32_t)(uint16_t)(y_mv + kHalf[k][4]) << 16) | (uint16_t)(x_mv + kHalf[k][3]);
-            *best_ssd = d;
+        if (method == METHOD_SSD) {
+            dist[k] = d;
+            if (d < *best_ssd) { /* strict '<', :1942 */
+                *best_sad = sad;  /* true SAD over all rows, :1943 */
+                *best_mv = ((uint32_t)(uint16_t)(y_mv + kHalf[k][4]) << 16) | (uint16_t)(x_mv + kHalf[k][3]);
+                *best_ssd = d;
+            }
+        } else {
+            /* :1930-1932: NxMSadKernel(src, stride << 1, ref, stride << 1, height >> 1, width) << 1, or all rows; compared with and stored
+             * as the best SAD (:1948-1953) */
+            const uint32_t dd = method == METHOD_SUB_SAD ? sad_even << 1 : sad;
+            dist[k] = dd;
+            if (dd < *best_sad) {
+                *best_sad = dd;
+                *best_mv = ((uint32_t)(uint16_t)(y_mv + kHalf[k][4]) << 16) | (uint16_t)(x_mv + kHalf[k][3]);
+            }
         }
     }
     /* direction: first match in the order L, R, T, B, TL, TR, BL, BR (:2209-2238; note BL before BR) */
@@ -208,7 +230,7 @@ static const int8_t kQuarter[4][8][2][3] = {
 
 static const int8_t kQmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
 
-static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo,
+static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo, int fsm,
                            uint32_t *best_sad, uint32_t *best_mv, uint32_t *best_ssd, uint8_t d)
 {
     const int16_t x_mv = (int16_t)(*best_mv & 0xffff), y_mv = (int16_t)(*best_mv >> 16);
@@ -238,7 +260,7 @@ static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r,
     for (int k = 0; k < 8; k++) {
         if (!valid[k]) continue;
         const int8_t(*q)[3] = kQuarter[method][k];
-        uint32_t ssd = 0, sad = 0;
+        uint32_t ssd = 0, sad = 0, sad_even = 0;
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++) {
                 const int p1 = sample(r, q[0][0], xs + px + x + q[0][1], ys + py + y + q[0][2]);
@@ -248,11 +270,20 @@ static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r,
                 const int e = sv - avg;
                 ssd += (uint32_t)(e * e); /* CombinedAveragingSSD: true SSD (:2792-2817) */
                 sad += (uint32_t)(e < 0 ? -e : e);
+                if (!(y & 1)) sad_even += (uint32_t)(e < 0 ? -e : e);
             }
-        if (ssd < *best_ssd) {
-            *best_sad = sad;
-            *best_mv = ((uint32_t)(uint16_t)(y_mv + kQmv[k][1]) << 16) | (uint16_t)(x_mv + kQmv[k][0]);
-            *best_ssd = ssd;
+        if (fsm == METHOD_SSD) {
+            if (ssd < *best_ssd) {
+                *best_sad = sad;
+                *best_mv = ((uint32_t)(uint16_t)(y_mv + kQmv[k][1]) << 16) | (uint16_t)(x_mv + kQmv[k][0]);
+                *best_ssd = ssd;
+            }
+        } else { /* :2915-2917, :2934-2939: NxMSadAveragingKernel on every second row << 1, or on all rows */
+            const uint32_t dd = fsm == METHOD_SUB_SAD ? sad_even << 1 : sad;
+            if (dd < *best_sad) {
+                *best_sad = dd;
+                *best_mv = ((uint32_t)(uint16_t)(y_mv + kQmv[k][1]) << 16) | (uint16_t)(x_mv + kQmv[k][0]);
+            }
         }
     }
 }
@@ -267,9 +298,9 @@ static const uint8_t kTab8[64] = {0,  1,  4,  5,  16, 17, 20, 21, 2,  3,  6,  7,
  *   src   : SB top-left in the padded source plane;  ref00: reference sample at search position (0,0)
  *   best_*: [85] ME-buffer order, in/out;  out_ssd/out_dir: optional [85] (final SSD, half-pel direction)
  *   disable_8x8: cu8x8_mode == CU_8x8_MODE_1 (8x8 PUs keep their full-pel result) */
-void orc_subpel_refine_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
-                            int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
-                            uint32_t *best_mv, uint32_t *out_ssd, uint8_t *out_dir)
+static void subpel_refine_85pu_m(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                                 int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, int method, uint32_t *best_sad,
+                                 uint32_t *best_mv, uint32_t *out_ssd, uint8_t *out_dir)
 {
     RefView r = {ref00, (int)ref_stride};
     const int xo = x_search_area_origin, yo = y_search_area_origin, ss = (int)src_stride;
@@ -277,35 +308,43 @@ void orc_subpel_refine_85pu(const uint8_t *src, uint32_t src_stride, const uint8
     uint8_t dir[85];
     for (int i = 0; i < 85; i++) { ssd[i] = 0; dir[i] = 0; }
     /* HalfPelSearch_LCU order: 64x64, 32x32[0..3], 16x16[raster 0..15], 8x8[raster 0..63] */
-    pu_half_pel(src, ss, &r, 0, 0, 64, 64, xo, yo, &best_sad[0], &best_mv[0], &ssd[0], &dir[0]);
+    pu_half_pel(src, ss, &r, 0, 0, 64, 64, xo, yo, method, &best_sad[0], &best_mv[0], &ssd[0], &dir[0]);
     for (int p = 0; p < 4; p++)
-        pu_half_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], &dir[1 + p]);
+        pu_half_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, method, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], &dir[1 + p]);
     for (int p = 0; p < 16; p++) {
         const int i = 5 + kTab16[p];
-        pu_half_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
+        pu_half_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, method, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
     }
     if (!disable_8x8)
         for (int p = 0; p < 64; p++) {
             const int i = 21 + kTab8[p];
-            pu_half_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
+            pu_half_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, method, &best_sad[i], &best_mv[i], &ssd[i], &dir[i]);
         }
     /* QuarterPelSearch_LCU: the 64x64 PU is refined with a 32x32 block at the SB origin (:3395-3409) */
-    pu_quarter_pel(src, ss, &r, 0, 0, 32, 32, xo, yo, &best_sad[0], &best_mv[0], &ssd[0], dir[0]);
+    pu_quarter_pel(src, ss, &r, 0, 0, 32, 32, xo, yo, method, &best_sad[0], &best_mv[0], &ssd[0], dir[0]);
     for (int p = 0; p < 4; p++)
-        pu_quarter_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], dir[1 + p]);
+        pu_quarter_pel(src, ss, &r, (p & 1) << 5, (p >> 1) << 5, 32, 32, xo, yo, method, &best_sad[1 + p], &best_mv[1 + p], &ssd[1 + p], dir[1 + p]);
     for (int p = 0; p < 16; p++) {
         const int i = 5 + kTab16[p];
-        pu_quarter_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
+        pu_quarter_pel(src, ss, &r, (p & 3) << 4, (p >> 2) << 4, 16, 16, xo, yo, method, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
     }
     if (!disable_8x8)
         for (int p = 0; p < 64; p++) {
             const int i = 21 + kTab8[p];
-            pu_quarter_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
+            pu_quarter_pel(src, ss, &r, (p & 7) << 3, (p >> 3) << 3, 8, 8, xo, yo, method, &best_sad[i], &best_mv[i], &ssd[i], dir[i]);
         }
     if (out_ssd)
         for (int i = 0; i < 85; i++) out_ssd[i] = ssd[i];
     if (out_dir)
         for (int i = 0; i < 85; i++) out_dir[i] = dir[i];
+}
+
+void orc_subpel_refine_85pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                            int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                            uint32_t *best_mv, uint32_t *out_ssd, uint8_t *out_dir)
+{
+    subpel_refine_85pu_m(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, METHOD_SSD, best_sad,
+                         best_mv, out_ssd, out_dir);
 }
 
 void orc_subpel_refine_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,
@@ -372,22 +411,48 @@ void orc_pu_geometry209(uint8_t *out)
 /* Sub-pel refinement of all 209 PUs of one SB against one list: the 85 squares as above, then the rectangular PUs
  * (HalfPelSearch_LCU :2418-2786, QuarterPelSearch_LCU :3580-4114; every PU is refined independently, so the order of
  * the calls does not matter).  Arrays are [209] in ME-buffer order.  Same pinning status as the 85-PU function. */
-void orc_subpel_refine_209pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
-                             int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
-                             uint32_t *best_mv)
+static void subpel_refine_209pu_m(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                                  int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, int method, uint32_t *best_sad,
+                                  uint32_t *best_mv, uint8_t *out_dir)
 {
-    orc_subpel_refine_85pu(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, best_sad, best_mv, 0, 0);
+    subpel_refine_85pu_m(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, method, best_sad, best_mv,
+                         0, out_dir);
     RefView r = {ref00, (int)ref_stride};
     const PuGeom *g = pu_geom209();
     for (int pu = 85; pu < 209; pu++) {
         const int n = g[pu].me;
         uint32_t ssd = 0;
         uint8_t dir = 0;
-        pu_half_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, &best_sad[n],
-                    &best_mv[n], &ssd, &dir);
-        pu_quarter_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, &best_sad[n],
-                       &best_mv[n], &ssd, dir);
+        pu_half_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, method,
+                    &best_sad[n], &best_mv[n], &ssd, &dir);
+        pu_quarter_pel(src, (int)src_stride, &r, g[pu].px, g[pu].py, g[pu].w, g[pu].h, x_search_area_origin, y_search_area_origin, method,
+                       &best_sad[n], &best_mv[n], &ssd, dir);
+        if (out_dir) out_dir[n] = dir;
     }
+}
+
+void orc_subpel_refine_209pu(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride,
+                             int16_t x_search_area_origin, int16_t y_search_area_origin, int disable_8x8, uint32_t *best_sad,
+                             uint32_t *best_mv)
+{
+    subpel_refine_209pu_m(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, METHOD_SSD, best_sad,
+                          best_mv, 0);
+}
+
+/* The refinement of one SB and list under any of the reference's three fractional search methods (0 SUB_SAD_SEARCH, 1 FULL_SAD_SEARCH,
+ * 2 SSD_SEARCH): 85 or 209 PUs in ME-buffer order, in/out; out_dir (optional): half-pel direction per PU, same order, reference codes
+ * (Codec/EbMotionEstimation.h:62-69).  Methods 0 and 1 are checked against the reference EXECUTING the same search
+ * (tests/test_subpel_vs_ref.py, oracle/ref_subpel_search_driver.c). */
+void orc_subpel_refine_method(const uint8_t *src, uint32_t src_stride, const uint8_t *ref00, uint32_t ref_stride, int16_t x_search_area_origin,
+                              int16_t y_search_area_origin, int disable_8x8, int all_pu, int method, uint32_t *best_sad, uint32_t *best_mv,
+                              uint8_t *out_dir)
+{
+    if (all_pu)
+        subpel_refine_209pu_m(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, method, best_sad,
+                              best_mv, out_dir);
+    else
+        subpel_refine_85pu_m(src, src_stride, ref00, ref_stride, x_search_area_origin, y_search_area_origin, disable_8x8, method, best_sad,
+                             best_mv, 0, out_dir);
 }
 
 void orc_subpel_refine209_batch(const uint8_t *src_plane, uint32_t src_stride, const uint8_t *ref_plane, uint32_t ref_stride,

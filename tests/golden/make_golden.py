@@ -317,7 +317,34 @@ def bipred_frac_fixture():
     np.savez_compressed(os.path.join(HERE, "bipred_frac.npz"), **out)
 
 
+def subpel_search_fixture():
+    """HalfPelSearch_LCU + QuarterPelSearch_LCU of the reference EXECUTED with fractionalSearchMethod = SUB_SAD_SEARCH / FULL_SAD_SEARCH
+    (oracle/ref_subpel_search_driver.c) on the full-pel results of a 192x128 picture's 6 SBs, 85 and 209 PUs: inputs and refined
+    (sad, mv, half-pel direction) per method -- the control flow of the sub-pel refinement, rows a11 / a12."""
+    from oracle.binding import Oracle, ReferenceSubpel
+    ref_sp, oracle = ReferenceSubpel(), Oracle()  # the oracle only supplies full-pel results (any values would do as inputs)
+    w, h = 192, 128
+    big = synth.synth_luma(2 * w + 64, 2 * h + 64, 0).astype(np.int32)
+    imgs = [((big[10:10 + 2 * h:2, 12:12 + 2 * w:2] + big[11:11 + 2 * h:2, 12:12 + 2 * w:2] + 1) >> 1).astype(np.uint8),
+            big[7:7 + 2 * h:2, 9:9 + 2 * w:2].astype(np.uint8)]
+    cur, ref = (synth.PaPicture(np.ascontiguousarray(x)) for x in imgs)
+    rng = np.random.default_rng(41)
+    nx, ny = cur.sb_grid()
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, rng.integers(-10, 11, (nx * ny, 2)), 40, 24)
+    out = dict(cur=imgs[0], ref=imgs[1], desc=desc)
+    for n_pu in (85, 209):
+        s0, m0 = (oracle.fullpel_search209_batch if n_pu == 209 else oracle.fullpel_search_batch)(cur.full, ref.full, desc)
+        out[f"sad0_{n_pu}"], out[f"mv0_{n_pu}"] = s0, m0
+        for method in (0, 1):
+            s, m, d = ref_sp.subpel_search(cur.full, ref.full, desc, s0, m0, method, n_pu == 209, asm_type=0)
+            s1, m1, d1 = ref_sp.subpel_search(cur.full, ref.full, desc, s0, m0, method, n_pu == 209, asm_type=1)
+            assert np.array_equal(s, s1) and np.array_equal(m, m1) and np.array_equal(d, d1)
+            out[f"sad_{n_pu}_m{method}"], out[f"mv_{n_pu}_m{method}"], out[f"dir_{n_pu}_m{method}"] = s, m, d
+    np.savez_compressed(os.path.join(HERE, "subpel_search.npz"), **out)
+
+
 if __name__ == "__main__":
+    subpel_search_fixture()
     bipred_frac_fixture()
     ois_fixture()
     convolve_fixture()

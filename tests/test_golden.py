@@ -403,3 +403,17 @@ def test_hip_bipred_fractional_matches_golden(hip_ctx, n_pu):
     hip_ctx.synchronize()
     res = d_out.cpu().numpy().view(svtav1_hip.ME_CU_RESULT_DTYPE).reshape(n_sb, n_pu)
     assert (res["direction"][:, :, 0] == 2).all() and np.array_equal(res["distortion"][:, :, 0], g[f"bisad_{n_pu}"])
+
+
+# ---- sub-pel refinement control flow: the reference's HalfPelSearch_LCU + QuarterPelSearch_LCU executed with the SAD search methods ----
+@pytest.mark.parametrize("n_pu", [85, 209])
+@pytest.mark.parametrize("method", [0, 1])
+def test_oracle_subpel_search_matches_golden(oracle, n_pu, method):
+    """tests/golden/subpel_search.npz holds what the reference itself computed (make_golden.py::subpel_search_fixture); this is the
+    check of rows a11 / a12's control flow that also runs where /root/reference does not exist."""
+    g = _load("subpel_search.npz")
+    cur, ref = synth.PaPicture(g["cur"]), synth.PaPicture(g["ref"])
+    s, m, d = oracle.subpel_refine_method(cur.full, ref.full, g["desc"], g[f"sad0_{n_pu}"], g[f"mv0_{n_pu}"], method, n_pu == 209)
+    assert np.array_equal(s, g[f"sad_{n_pu}_m{method}"]) and np.array_equal(m, g[f"mv_{n_pu}_m{method}"])
+    assert np.array_equal(d, g[f"dir_{n_pu}_m{method}"])
+    assert (m != g[f"mv0_{n_pu}"]).mean() > 0.05  # the fixture really refines

@@ -224,3 +224,88 @@ def test_8_wide_rectangles_use_the_8_row_metric(oracle):
     diff = (m_ref != m_all) | (s_ref != s_all)
     assert diff[:, narrow].any(), "the 8-row metric must change some 8x16 / 8x32 result on random pictures"
     assert not diff[:, ~narrow].any(), "every other shape class is independent of the fix"
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The refinement's CONTROL FLOW against the reference executing it.  MeContext_t::fractionalSearchMethod selects the distortion at run
+# time; with SUB_SAD_SEARCH (0) / FULL_SAD_SEARCH (1) the reference's HalfPelSearch_LCU + QuarterPelSearch_LCU run here (Log2f_SSE2 is
+# only evaluated by the SSD_SEARCH branch of the conditional operator), statement for statement the code the SSD method runs too.
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def refsubpel():
+    from oracle.binding import ReferenceSubpel
+    if not ReferenceSubpel.available():
+        pytest.skip("oracle/_ref/libsvtref_subpel.so not built")
+    return ReferenceSubpel()
+
+
+def _search_case(kind, w=256, h=192, seed=5):
+    rng = np.random.default_rng(seed)
+    if kind == "synth":
+        f = [synth.synth_luma(w, h, 2), synth.synth_luma(w, h, 0)]
+    elif kind == "pan":  # a sub-pel pan: the refinement really moves
+        big = synth.synth_luma(2 * w + 64, 2 * h + 64, 0).astype(np.int32)
+        f = [((big[10:10 + 2 * h:2, 12:12 + 2 * w:2] + big[11:11 + 2 * h:2, 12:12 + 2 * w:2] + 1) >> 1).astype(np.uint8),
+             big[7:7 + 2 * h:2, 9:9 + 2 * w:2].astype(np.uint8)]
+    elif kind == "coarse":  # few grey levels: exact ties between candidates, everywhere
+        f = [(rng.integers(0, 3, (h, w)) * 100).astype(np.uint8), (rng.integers(0, 3, (h, w)) * 100).astype(np.uint8)]
+    elif kind == "flat":
+        f = [np.full((h, w), 90, np.uint8), np.full((h, w), 90, np.uint8)]
+    else:
+        f = [rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h, w), dtype=np.uint8)]
+    return synth.PaPicture(np.ascontiguousarray(f[0])), synth.PaPicture(np.ascontiguousarray(f[1]))
+
+
+@pytest.mark.parametrize("all_pu", [False, True])
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("kind", ["synth", "pan", "coarse", "flat", "random"])
+def test_refinement_control_flow_matches_reference_execution(oracle, refsubpel, kind, method, all_pu):
+    cur, ref = _search_case(kind)
+    rng = np.random.default_rng(17)
+    nx, ny = cur.sb_grid()
+    centers = rng.integers(-12, 13, size=(nx * ny, 2))
+    sw, sh = (24, 16) if kind in ("random", "coarse") else (40, 32)
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, centers, sw, sh)
+    if all_pu:
+        s0, m0 = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    else:
+        s0, m0 = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    for asm_type in (0, 1):
+        s_r, m_r, d_r = refsubpel.subpel_search(cur.full, ref.full, desc, s0, m0, method, all_pu, asm_type=asm_type)
+        s_o, m_o, d_o = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, method, all_pu)
+        bad = np.argwhere((s_r != s_o) | (m_r != m_o) | (d_r != d_o))
+        assert bad.size == 0, (f"asm {asm_type}: {len(bad)} mismatches, first (sb, ME index) {bad[0]}: reference sad/mv/dir "
+                               f"{s_r[tuple(bad[0])]}/{m_r[tuple(bad[0])]:#x}/{d_r[tuple(bad[0])]} oracle {s_o[tuple(bad[0])]}/{m_o[tuple(bad[0])]:#x}/{d_o[tuple(bad[0])]}")
+    if kind in ("synth", "pan"):
+        assert (m_o != m0).mean() > 0.05, "the case must actually move vectors to sub-pel positions"
+
+
+def test_refinement_with_8x8_disabled_matches_reference_execution(oracle, refsubpel):
+    """cu8x8_mode == CU_8x8_MODE_1: the 8x8 PUs keep their full-pel result (:2375, :3470)."""
+    cur, ref = _search_case("pan")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 32, 32)
+    s0, m0 = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    s_r, m_r, d_r = refsubpel.subpel_search(cur.full, ref.full, desc, s0, m0, 0, False, disable_8x8=True)
+    s_o, m_o, d_o = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 0, False, disable_8x8=True)
+    assert np.array_equal(s_r, s_o) and np.array_equal(m_r, m_o)
+    assert np.array_equal(m_o[:, 21:], m0[:, 21:])
+
+
+def test_ssd_method_runs_the_same_functions(oracle):
+    """The SSD method (what MotionEstimateLcu hard-wires, :6254) goes through the very functions pinned above -- pu_half_pel /
+    pu_quarter_pel of oracle/svt_subpel_oracle.c take the method as an argument and differ only in the distortion lines, whose leaves and
+    per-shape dispatch are pinned separately (test_half_pel_leaf_dispatch_per_shape, test_quarter_pel_leaf_dispatch_per_shape).  Here:
+    method 2 through the general entry equals the 85- / 209-PU entries the GPU tests and golden fixtures use."""
+    cur, ref = _search_case("pan")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 32, 32)
+    s0, m0 = oracle.fullpel_search_batch(cur.full, ref.full, desc)
+    s_a, m_a, _, d_a = oracle.subpel_refine_batch(cur.full, ref.full, desc, s0, m0)
+    s_b, m_b, d_b = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 2, False)
+    assert np.array_equal(s_a, s_b) and np.array_equal(m_a, m_b) and np.array_equal(d_a, d_b)
+    s0, m0 = oracle.fullpel_search209_batch(cur.full, ref.full, desc)
+    s_a, m_a = oracle.subpel_refine209_batch(cur.full, ref.full, desc, s0, m0)
+    s_b, m_b, _ = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 2, True)
+    assert np.array_equal(s_a, s_b) and np.array_equal(m_a, m_b)
+    # and the three methods really are different searches on this content
+    s_c, m_c, _ = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 0, True)
+    assert (m_c != m_b).any() or (s_c != s_b).any()
