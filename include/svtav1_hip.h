@@ -182,6 +182,25 @@ int32_t svthip_me_subpel_refine_dev(svthip_ctx *ctx, const uint8_t *d_src_plane,
                                     uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
                                     int32_t disable_8x8_refinement, uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
 
+/* The same refinement with the distortion selectable like MeContext_t::fractionalSearchMethod (Codec/EbMotionEstimationContext.h:392,
+ * values Codec/EbDefinitions.h:1846-1848), for the 85 squares (all_pu = 0) or all 209 PUs (all_pu != 0, [n_sb][209] arrays):
+ *   SUB_SAD_SEARCH  : every candidate costs 2 x its SAD over every second row (NxMSadKernel / NxMSadAveragingKernel with doubled strides
+ *                     and half the height, :1930-1931, :2915-2916), compared with and stored as the best SAD;
+ *   FULL_SAD_SEARCH : the SAD over every row (:1932, :2917);
+ *   SSD_SEARCH      : what MotionEstimateLcu hard-wires (:6254) and the two entries above / below compute.
+ * The statements around the distortion -- candidate order, strict '<', direction choice, valid quarter-pel positions, buffer selection --
+ * are shared by the three methods; with the SAD methods the reference's own HalfPelSearch_LCU + QuarterPelSearch_LCU can be executed in the
+ * build container (no NASM-only symbol is reached) and this entry is checked against them.  (The per-PU-tile kernels that
+ * SVTHIP_SUBPEL_TILES=1 selects for A/B runs implement SSD_SEARCH only and return SVTHIP_ERR_BAD_PARAMETER for the SAD methods.) */
+#define SVTHIP_FRACTIONAL_SUB_SAD_SEARCH 0
+#define SVTHIP_FRACTIONAL_FULL_SAD_SEARCH 1
+#define SVTHIP_FRACTIONAL_SSD_SEARCH 2
+int32_t svthip_me_subpel_search_dev(svthip_ctx *ctx, const uint8_t *d_src_plane, uint32_t src_stride,
+                                    const uint8_t *d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc *d_desc,
+                                    uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
+                                    int32_t disable_8x8_refinement, int32_t all_pu, int32_t fractional_search_method,
+                                    uint32_t *d_best_sad, uint32_t *d_best_mv, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bi-prediction SAD + result packing for a batch of superblocks.
  * Replaces the tail of MotionEstimateLcu (Codec/EbMotionEstimation.c:6973-7146): BiPredictionSearch /

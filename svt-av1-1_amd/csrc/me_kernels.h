@@ -61,7 +61,7 @@ __global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t 
 size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                      uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
-                                     uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out);
+                                     uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out, int method);
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                   uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,

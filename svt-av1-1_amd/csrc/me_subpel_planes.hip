@@ -95,6 +95,7 @@ struct Ctx {
     uint32_t* pred;            // this SB's prediction slots ([slots][1024 dwords], slots in the class order above), or null
     lds_u32* shake;            // hand-shake area of the 64x64 PU (two waves): 17 half-pel sums, 6 quarter-pel sums, 2 arrival counters
     int lane;
+    int method;                // MeContext_t::fractionalSearchMethod: 0 SUB_SAD_SEARCH, 1 FULL_SAD_SEARCH, 2 SSD_SEARCH (wave-uniform)
 };
 
 // LDS byte address of plane p at search coordinates (x, y), and that plane's pitch
@@ -110,7 +111,9 @@ __device__ __forceinline__ uint32_t plane_addr(const Planes& P, int p, int x, in
 // 8 * half + g, lane & 7 = the row inside a cell.  The 4 cells of a chunk sit at compile-time offsets from the chunk's first cell
 // (CW >= 4: a row of four; CW = 2: 2 x 2; CW = 1: a column), so every LDS address is `row base + immediate (+ k * 8 pitches)` and the
 // byte shift of an unaligned row is the same for all cells of a PU (cell offsets are multiples of 8 bytes and of 8 pitches).
-template <int W, int H, int CLS>
+// SADM: one of the SAD search methods (c.method 0 / 1) instead of SSD_SEARCH -- a template parameter so that the SSD instantiation, the
+// one MotionEstimateLcu uses, carries none of the other methods' code (as a run-time branch it cost 136 bytes of scratch and 3-5 %).
+template <int W, int H, int CLS, bool SADM>
 __device__ void refine_class_half(const Ctx& c, int half, bool refine)
 {
     constexpr int CW = W / 8, CPP = CW * (H / 8);                 // cells per PU
@@ -167,6 +170,13 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
                     if (k < 8) sad[k] = __builtin_amdgcn_sad_u8(sv.y, cand[k][1], __builtin_amdgcn_sad_u8(sv.x, cand[k][0], sad[k]));
                 }
             }
+            // The SAD search methods compare (and store) SADs instead: NxMSadKernel over every row, or over every second row (this
+            // lane's row r is even) doubled (:1930-1932).  Same reductions, same decision code below; only the metric differs.
+            constexpr bool sad_method = SADM;
+            if (sad_method) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) ssd[k] = (c.method == 0 && (r & 1)) ? 0u : sad[k];
+            }
 #pragma unroll
             for (int k = 0; k < 9; k++) ssd[k] = gsum<LPP>(ssd[k]);
 #pragma unroll
@@ -185,14 +195,26 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
 #pragma unroll
                 for (int k = 0; k < 8; k++) sad[k] = __hip_atomic_load(c.shake + 9 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            best_ssd = ssd[8];  // SSD of the best full-pel candidate (:1912)
             const int mvdx[8] = {-2, 2, 0, 0, -2, 2, 2, -2}, mvdy[8] = {0, 0, -2, 2, -2, -2, 2, 2};
+            if (sad_method) {
+                // the candidate's distortion is compared with, and stored as, the best SAD (:1948-1953); there is no SSD state
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (ssd[k] < best_ssd) {  // strict '<' (:1942)
-                    best_sad = sad[k];
-                    best_mv = ((uint32_t)(uint16_t)(y_mv + mvdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + mvdx[k]);
-                    best_ssd = ssd[k];
+                for (int k = 0; k < 8; k++) {
+                    if (c.method == 0) ssd[k] <<= 1;
+                    if (ssd[k] < best_sad) {
+                        best_sad = ssd[k];
+                        best_mv = ((uint32_t)(uint16_t)(y_mv + mvdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + mvdx[k]);
+                    }
+                }
+            } else {
+                best_ssd = ssd[8];  // SSD of the best full-pel candidate (:1912)
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (ssd[k] < best_ssd) {  // strict '<' (:1942)
+                        best_sad = sad[k];
+                        best_mv = ((uint32_t)(uint16_t)(y_mv + mvdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + mvdx[k]);
+                        best_ssd = ssd[k];
+                    }
                 }
             }
             uint32_t m = ssd[0];
@@ -261,7 +283,9 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
             }
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                qssd[t] = gsum<LPP>(qsrc2 + qssd[t] - 2u * qsv[t]);  // per lane a sum of squares: never negative
+                // SSD method: per lane a sum of squares, never negative; SAD methods: NxMSadAveragingKernel on all / every second row (:2915-2917)
+                const uint32_t lane_metric = sad_method ? ((c.method == 0 && (r & 1)) ? 0u : qsad[t]) : qsrc2 + qssd[t] - 2u * qsv[t];
+                qssd[t] = gsum<LPP>(lane_metric);
                 qsad[t] = gsum<LPP>(qsad[t]);
             }
             if (TWO_WAVES) {
@@ -284,7 +308,13 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
             for (int t = 0; t < 3; t++) {
                 // L, R, T, B, TL, TR, BR, BL: dx = {-1, 1, 0, 0, -1, 1, 1, -1}, dy = {0, 0, -1, 1, -1, -1, 1, 1}, two bits each (+1)
                 const int qdx = (int)((0x2858u >> (2 * qk[t])) & 3u) - 1, qdy = (int)((0xA085u >> (2 * qk[t])) & 3u) - 1;
-                if (qssd[t] < best_ssd) {
+                if (sad_method) {
+                    const uint32_t dist = c.method == 0 ? qssd[t] << 1 : qssd[t];
+                    if (dist < best_sad) {  // :2934-2939
+                        best_sad = dist;
+                        best_mv = ((uint32_t)(uint16_t)(hy + qdy) << 16) | (uint32_t)(uint16_t)(hx + qdx);
+                    }
+                } else if (qssd[t] < best_ssd) {
                     best_sad = qsad[t];
                     best_mv = ((uint32_t)(uint16_t)(hy + qdy) << 16) | (uint32_t)(uint16_t)(hx + qdx);
                     best_ssd = qssd[t];
@@ -323,7 +353,8 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
 template <int CLS>
 __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
 {
-    refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS>(c, half, refine);
+    if (c.method == 2) refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, false>(c, half, refine);
+    else refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, true>(c, half, refine);
 }
 
 }  // namespace
@@ -333,7 +364,8 @@ __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
 __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                             const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                                             const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
-                                                            uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out)
+                                                            uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out,
+                                                            int method)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
@@ -459,6 +491,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.pred = pred_out ? pred_out + (size_t)sb * (n_pu == 209 ? 14 : 4) * 1024 : nullptr;
     c.shake = ctl + 4;
     c.lane = lane;
+    c.method = __builtin_amdgcn_readfirstlane(method);
     const int n_tasks = n_pu == 209 ? 28 : 8;
 #pragma unroll 1
     for (int task = wave; task < n_tasks; task += n_waves) {

@@ -199,9 +199,12 @@ int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane
 static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
                                      uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_search_area_width,
                                      uint32_t max_search_area_height, int32_t disable_8x8_refinement, int n_pu, uint32_t* d_best_sad,
-                                     uint32_t* d_best_mv, void* stream, uint32_t* d_pred = nullptr)
+                                     uint32_t* d_best_mv, void* stream, uint32_t* d_pred = nullptr,
+                                     int32_t method = SVTHIP_FRACTIONAL_SSD_SEARCH)
 {
     ENTER(ctx);
+    if (method != SVTHIP_FRACTIONAL_SUB_SAD_SEARCH && method != SVTHIP_FRACTIONAL_FULL_SAD_SEARCH && method != SVTHIP_FRACTIONAL_SSD_SEARCH)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "fractional_search_method must be 0 (SUB_SAD), 1 (FULL_SAD) or 2 (SSD)%s, got %d", "", (int)method);
     if (n_sb == 0) return SVTHIP_OK;
     if (!d_src_plane || !d_ref_plane || !d_desc || !d_best_sad || !d_best_mv)
         return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
@@ -215,11 +218,13 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
     if (lds_planes <= 160 * 1024 - 512 && !getenv("SVTHIP_SUBPEL_TILES")) {
         hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
                            d_ref_plane, ref_stride, reinterpret_cast<const int32_t*>(d_desc), n_sb, (int)(disable_8x8_refinement != 0), n_pu,
-                           d_best_sad, d_best_mv, d_pred);
+                           d_best_sad, d_best_mv, d_pred, (int)method);
         HIP_TRY(hipGetLastError());
         return SVTHIP_OK;
     }
-    // search areas beyond ~120 x 120: per-PU tiles (me_subpel.hip)
+    // per-PU tiles (me_subpel.hip; SVTHIP_SUBPEL_TILES=1, or planes that do not fit): SSD_SEARCH only, the method MotionEstimateLcu uses
+    if (method != SVTHIP_FRACTIONAL_SSD_SEARCH)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "the SAD search methods are implemented by the plane kernel only%s (method %d)", "", (int)method);
     const size_t lds = svthip::subpel_lds_bytes(max_search_area_width, max_search_area_height);
     const size_t lds_nsq = svthip::subpel_nsq_lds_bytes(max_search_area_width, max_search_area_height);
     if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
@@ -251,6 +256,16 @@ int32_t svthip_me_subpel_refine209_dev(svthip_ctx* ctx, const uint8_t* d_src_pla
 {
     return subpel_refine_common(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
                                 max_search_area_height, disable_8x8_refinement, 209, d_best_sad, d_best_mv, stream);
+}
+
+int32_t svthip_me_subpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref_plane,
+                                    uint32_t ref_stride, const svthip_fullpel_desc* d_desc, uint32_t n_sb, uint32_t max_search_area_width,
+                                    uint32_t max_search_area_height, int32_t disable_8x8_refinement, int32_t all_pu,
+                                    int32_t fractional_search_method, uint32_t* d_best_sad, uint32_t* d_best_mv, void* stream)
+{
+    return subpel_refine_common(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
+                                max_search_area_height, disable_8x8_refinement, all_pu ? 209 : 85, d_best_sad, d_best_mv, stream, nullptr,
+                                fractional_search_method);
 }
 
 static int32_t bipred_pack_common(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride, const uint8_t* d_ref0_plane,

@@ -91,6 +91,9 @@ def lib() -> C.CDLL:
                                             C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
     L.svthip_me_subpel_refine209_dev.restype = C.c_int32
     L.svthip_me_subpel_refine209_dev.argtypes = L.svthip_me_subpel_refine_dev.argtypes
+    L.svthip_me_subpel_search_dev.restype = C.c_int32
+    L.svthip_me_subpel_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.svthip_me_bipred_pack209_dev.restype = C.c_int32
     L.svthip_me_bipred_pack209_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                                C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -291,6 +294,19 @@ def _subpel_refine209_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_
     """Sub-pel refinement of all 209 PUs; d_sad / d_mv: [n_sb][209] uint32 device arrays (ME-buffer order), in place."""
     _check(lib().svthip_me_subpel_refine209_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh,
                                                 int(disable_8x8), d_sad, d_mv, stream))
+
+
+FRACTIONAL_SUB_SAD_SEARCH, FRACTIONAL_FULL_SAD_SEARCH, FRACTIONAL_SSD_SEARCH = 0, 1, 2  # MeContext_t::fractionalSearchMethod
+
+
+def _subpel_search_dev(self, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh, d_sad, d_mv, method, all_pu,
+                       disable_8x8=False, stream=None):
+    """The refinement under one of the reference's fractional search methods; d_sad / d_mv: [n_sb][209 if all_pu else 85], in place."""
+    _check(lib().svthip_me_subpel_search_dev(self._h, d_src, src_stride, d_ref, ref_stride, d_desc, n_sb, max_sw, max_sh,
+                                             int(disable_8x8), int(all_pu), int(method), d_sad, d_mv, stream))
+
+
+Context.subpel_search_dev = _subpel_search_dev
 
 
 def _bipred_pack209_dev(self, d_src, src_stride, d_ref0, ref0_stride, d_desc0, d_ref1, ref1_stride, d_desc1, n_sb, max_sw, max_sh,

@@ -149,3 +149,61 @@ def test_subpel209_8_wide_rectangles_follow_the_8_row_ssd(hip_ctx, oracle):
     assert narrow.sum() == 48
     differs = (m_h != m_all) | (s_h != s_all)
     assert differs[:, narrow].any() and not differs[:, ~narrow].any()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The reference's three fractional search methods through svthip_me_subpel_search_dev.  Methods 0 / 1 (SUB_SAD / FULL_SAD) run the same
+# control flow as SSD_SEARCH with SAD leaves, and for them the expected values are pinned against the reference EXECUTING its own
+# HalfPelSearch_LCU + QuarterPelSearch_LCU (tests/test_subpel_vs_ref.py, tests/golden/subpel_search.npz).
+# ------------------------------------------------------------------------------------------------------------------------------
+def _run_search(ctx, cur, ref, desc, sad0, mv0, method, all_pu, disable_8x8=False):
+    import torch
+    dev = torch.device("cuda:0")
+    d_src, d_ref, d_desc = torch.from_numpy(cur.full).to(dev), torch.from_numpy(ref.full).to(dev), torch.from_numpy(desc).to(dev)
+    d_sad = torch.from_numpy(sad0.view(np.int32).copy()).to(dev)
+    d_mv = torch.from_numpy(mv0.view(np.int32).copy()).to(dev)
+    torch.cuda.synchronize()
+    ctx.subpel_search_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), desc.shape[0],
+                          int(desc[:, 4].max()), int(desc[:, 5].max()), d_sad.data_ptr(), d_mv.data_ptr(), method, all_pu, disable_8x8)
+    ctx.synchronize()
+    return d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("all_pu", [False, True])
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("kind,search", [("smooth", (64, 64)), ("synth", (40, 24)), ("extreme", (23, 9)), ("flat", (16, 16)), ("random", (64, 64))])
+def test_subpel_search_methods_match_oracle(hip_ctx, oracle, kind, search, method, all_pu):
+    pytest.importorskip("torch")
+    cur, ref = _pictures(192, 136, kind)
+    rng = np.random.default_rng(29)
+    nx, ny = cur.sb_grid()
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, rng.integers(-20, 21, size=(nx * ny, 2)), *search)
+    s0, m0 = (oracle.fullpel_search209_batch if all_pu else oracle.fullpel_search_batch)(cur.full, ref.full, desc)
+    s_o, m_o, _ = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, method, all_pu)
+    s_h, m_h = _run_search(hip_ctx, cur, ref, desc, s0, m0, method, all_pu)
+    bad = np.argwhere((s_h != s_o) | (m_h != m_o))
+    assert bad.size == 0, f"{len(bad)} mismatches, first (sb,pu)={bad[0]}: hip {s_h[tuple(bad[0])]}/{m_h[tuple(bad[0])]:#x} oracle {s_o[tuple(bad[0])]}/{m_o[tuple(bad[0])]:#x}"
+
+
+@pytest.mark.parametrize("n_pu", [85, 209])
+@pytest.mark.parametrize("method", [0, 1])
+def test_subpel_search_matches_reference_execution(hip_ctx, n_pu, method):
+    """HIP against what the REFERENCE ITSELF computed (tests/golden/subpel_search.npz, generated by running HalfPelSearch_LCU +
+    QuarterPelSearch_LCU of /root/reference with the SAD search methods): no oracle in between."""
+    import os
+    pytest.importorskip("torch")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "subpel_search.npz"))
+    cur, ref = synth.PaPicture(g["cur"]), synth.PaPicture(g["ref"])
+    s_h, m_h = _run_search(hip_ctx, cur, ref, g["desc"], g[f"sad0_{n_pu}"], g[f"mv0_{n_pu}"], method, n_pu == 209)
+    assert np.array_equal(s_h, g[f"sad_{n_pu}_m{method}"]) and np.array_equal(m_h, g[f"mv_{n_pu}_m{method}"])
+
+
+def test_subpel_search_rejects_bad_methods(hip_ctx):
+    import torch
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda:0")
+    out = torch.zeros(1 << 12, dtype=torch.int32, device="cuda:0")
+    p = buf.data_ptr()
+    with pytest.raises(svtav1_hip.SvtHipError, match="fractional_search_method"):
+        hip_ctx.subpel_search_dev(p, 256, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr(), 3, False)
+    with pytest.raises(svtav1_hip.SvtHipError, match="fractional_search_method"):
+        hip_ctx.subpel_search_dev(p, 256, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr(), -1, True)
