@@ -13,10 +13,15 @@
  * (tests/test_subpel_vs_ref.py).  The leaf DISPATCH is pinned per (width, height): orc_halfpel_ssd_dispatched /
  * orc_halfpel_sad_dispatched / orc_quarterpel_*_dispatched below restate which table entry PU_HalfPelRefinement /
  * PU_QuarterPelRefinementOnTheFly index for a PU size, and tests/test_subpel_vs_ref.py compares them with the reference's
- * own function-pointer tables (oracle/ref_subpel_leaf_driver.c) for every (w,h) pair HalfPelSearch_LCU passes.  The per-PU refinement CONTROL FLOW (PU_HalfPelRefinement and the quarter-pel
- * functions) is restated from the source text only: the reference's sub-pel path calls Log2f_SSE2, which exists
- * only in a NASM file this image cannot assemble, so it cannot be executed here -- "parity unpinned" for that
- * control flow (DESIGN.md "oracle").
+ * own function-pointer tables (oracle/ref_subpel_leaf_driver.c) for every (w,h) pair HalfPelSearch_LCU passes.
+ * The per-PU refinement CONTROL FLOW (PU_HalfPelRefinement, PU_QuarterPelRefinementOnTheFly and the two _LCU drivers with their index
+ * maps) is pinned against the reference EXECUTING it: the distortion is a run-time choice (MeContext_t::fractionalSearchMethod), and with
+ * SUB_SAD_SEARCH / FULL_SAD_SEARCH the reference's HalfPelSearch_LCU + QuarterPelSearch_LCU run in this image (Log2f_SSE2, NASM-only, is
+ * evaluated only by the SSD_SEARCH branch of a conditional operator): oracle/ref_subpel_search_driver.c, tests/test_subpel_vs_ref.py
+ * ::test_refinement_control_flow_matches_reference_execution, tests/golden/subpel_search.npz.  pu_half_pel / pu_quarter_pel below take the
+ * method as an argument and differ between methods only in the distortion lines.  What stays unexecuted by the reference here is the
+ * SSD_SEARCH distortion INSIDE that control flow (MotionEstimateLcu's setting): its leaves and dispatch are pinned as said above, the
+ * bookkeeping of pBestSsd (:1911-1919, :1941-1946, :2927-2932) is restated from the text.
  */
 #include "svt_me_oracle.h"
 
