@@ -151,8 +151,10 @@ __device__ void wave_sad_loop_generic(const uint8_t* src, uint32_t src_stride, c
         best = key < best ? key : best;  // a lane visits its positions in raster order
     }
     best = wave_min_u64(best);
-    const uint32_t pos = (uint32_t)best;
-    *best_sad = (uint32_t)(best >> 32);
+    // every lane holds the same minimum: hand it on in scalar registers, so that the origin arithmetic, window clipping and loop bounds
+    // of the next level are scalar code instead of vector code under exec masks
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)best);
+    *best_sad = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best >> 32));
     *by = (int)(pos / (uint32_t)sw);
     *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
 }
@@ -332,8 +334,8 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     } else {
         best = wave_min_u64(best);
     }
-    const uint32_t pos = (uint32_t)best;
-    *best_sad = (uint32_t)(best >> 32);
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)best);  // wave-uniform: scalar from here on
+    *best_sad = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best >> 32));
     *by = (int)(pos / (uint32_t)sw);
     *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
 }
@@ -423,6 +425,7 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
+    best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);  // wave-uniform: scalar from here on
     const uint32_t pos = best & 0xffffu;
     *best_sad = best >> 16;
     *by = (int)(pos / (uint32_t)sw);
