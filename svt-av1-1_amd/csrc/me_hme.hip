@@ -46,6 +46,10 @@ extern "C" int svthip_debug_hme_stamps(void* host, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hme_stamps), bytes < sizeof(g_hme_stamps) ? bytes : sizeof(g_hme_stamps));
 }
+extern "C" int svthip_debug_hme_loop_phases(unsigned long long* host8)
+{
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_hme_loop_phase), sizeof(g_hme_loop_phase));
+}
 #endif
 
 }  // namespace svthip

@@ -47,8 +47,17 @@ __device__ unsigned long long g_hme_stamps[8192 * 4 * 8];
     do {                                                                                                                      \
         if (lane == 0 && sbi < 8192u) g_hme_stamps[((size_t)sbi * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+// sub-phases of wave_sad_loop_lds, summed over all waves of the launches since load: [W == 64][staging, search loop, tail, calls]
+__device__ unsigned long long g_hme_loop_phase[2 * 4];
+#define HME_LOOP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define HME_LOOP_ADD(slot, t1, t0)                                                                                \
+    do {                                                                                                          \
+        if (lane == 0) atomicAdd(&g_hme_loop_phase[(W == 64 ? 4 : 0) + (slot)], (unsigned long long)((t1) - (t0))); \
+    } while (0)
 #else
 #define HME_STAMP(i) do { } while (0)
+#define HME_LOOP_T(var) do { } while (0)
+#define HME_LOOP_ADD(slot, t1, t0) do { } while (0)
 #endif
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -259,9 +268,12 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     for (int y0 = 0; y0 < sh; y0 += band) {
         const int bh = min(band, sh - y0);
         const int wrows = bh + 2 * H - 2;
+        HME_LOOP_T(t_a);
         stage_window_rows(ref + (size_t)y0 * ref_stride_raw, ref_stride_raw, wrows, pitch, win, lane);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HME_LOOP_T(t_b);
+        HME_LOOP_ADD(0, t_b, t_a);
 
         const int nitems = items_row * bh;
         int RP = 1, rp_shift = 0;
@@ -326,7 +338,10 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
             }
         }
         __builtin_amdgcn_wave_barrier();
+        HME_LOOP_T(t_c);
+        HME_LOOP_ADD(1, t_c, t_b);
     }
+    HME_LOOP_T(t_d);
     if (KEY32) {
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) best32 = min(best32, (uint32_t)__shfl_xor((int)best32, m));
@@ -338,6 +353,9 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
     *best_sad = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(best >> 32));
     *by = (int)(pos / (uint32_t)sw);
     *bx = (int)(pos - (uint32_t)(*by) * (uint32_t)sw);
+    HME_LOOP_T(t_e);
+    HME_LOOP_ADD(2, t_e, t_d);
+    HME_LOOP_ADD(3, 1ull, 0ull);
 }
 
 // SadLoopKernel of HME level 0 (16 x 8-row block on the 1/16 plane; ~70 % of the search-centre work), one wave.

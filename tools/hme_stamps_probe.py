@@ -49,3 +49,13 @@ tot = (st[full][:, :, 6].astype(np.int64) - st[full][:, :, 0].astype(np.int64)).
 print(f"{'whole chain':22s} median {np.median(tot):9.0f} ticks")
 span = int(st[full][:, :, 6].max() - st[full][:, :, 0].min())
 print("launch span", span, "ticks")
+
+# sub-phases of the level-1 / level-2 SAD loop (wave_sad_loop_lds), averaged per call
+ph = np.zeros(8, np.uint64)
+g = svtav1_hip.lib().svthip_debug_hme_loop_phases
+g.restype = C.c_int
+g.argtypes = [C.c_void_p]
+assert g(ph.ctypes.data) == 0
+for lvl, o in (("level 1 (W = 32)", 0), ("level 2 (W = 64)", 4)):
+    calls = max(int(ph[o + 3]), 1)
+    print(f"{lvl}: per call: window staging {int(ph[o]) / calls:8.0f}  search loop {int(ph[o + 1]) / calls:8.0f}  wave minimum + decode {int(ph[o + 2]) / calls:8.0f} ticks ({calls} calls)")
