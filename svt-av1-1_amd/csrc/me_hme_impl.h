@@ -185,23 +185,25 @@ __device__ __forceinline__ void stage_window_rows(const uint8_t* base, uint32_t 
 {
     // A lane moves FOUR consecutive dwords of a row: one 16-byte global load at the row's own byte alignment (no alignment needed on
     // this target; round 2 used five aligned dwords + four v_alignbyte) and four LDS stores.  lpr lanes per row, rpp rows per wave
-    // pass, two passes in flight.
+    // pass, NP passes in flight: the level-1 / level-2 windows (46 / 70 rows) are then ONE round trip to memory instead of two / three
+    // -- these levels spend most of their wall time waiting for this copy (tools/hme_stamps_probe.py).
+    constexpr int NP = 6;
     const int lpr = (pitch + 3) >> 2;
     const int rpp = lpr < 64 ? 64 / lpr : 1;
     const int g = (int)(((uint32_t)lane * ((1u << 16) / (uint32_t)lpr + 1u)) >> 16), q4 = 4 * (lane - g * lpr);
     const bool lane_ok = g < rpp;
     const uintptr_t a0 = reinterpret_cast<uintptr_t>(base) + 4u * (uint32_t)q4;
-    for (int r0 = g; r0 < wrows; r0 += 2 * rpp) {
-        gmem_u32x4 w[2];
+    for (int r0 = g; r0 < wrows; r0 += NP * rpp) {
+        gmem_u32x4 w[NP];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NP; u++) {
             const int r = min(r0 + u * rpp, wrows - 1);  // clamped: the loads stay unconditional and in flight together
             const __attribute__((address_space(1))) gmem_u32x4* q = (const __attribute__((address_space(1))) gmem_u32x4*)(a0 + (size_t)r * ref_stride_raw);
 #pragma unroll
             for (int k = 0; k < 4; k++) w[u].v[k] = q->v[k];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NP; u++) {
             const int r = r0 + u * rpp;
             if (lane_ok && r < wrows) {
                 uint32_t* o = win + r * pitch + q4;
