@@ -482,7 +482,7 @@ __device__ __forceinline__ int round_hme_width(int w)
     return (w < 8) ? 8 : ((w & 7) ? (w + (w - ((w >> 3) << 3))) : w);  // :4528 (adds the remainder, sic)
 }
 
-constexpr int kHmeLdsPerWave = 8 * 1024;  // per-wave LDS slice: source block + a band of the search window
+constexpr int kHmeLdsPerWave = 6 * 1024;  // per-wave LDS slice: source block + a band of the search window
 
 struct HmeShared {
     unsigned long long cost[8];   // centre-check candidate costs
