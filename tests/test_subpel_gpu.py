@@ -207,3 +207,34 @@ def test_subpel_search_rejects_bad_methods(hip_ctx):
         hip_ctx.subpel_search_dev(p, 256, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr(), 3, False)
     with pytest.raises(svtav1_hip.SvtHipError, match="fractional_search_method"):
         hip_ctx.subpel_search_dev(p, 256, p, 256, p, 1, 64, 64, out.data_ptr(), out.data_ptr(), -1, True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_subpel_search_sad_methods_1080p(hip_ctx, oracle, method):
+    """Full BASELINE size, all 209 PUs of the 510 SBs under the SAD search methods: a sample against the (reference-pinned) oracle, and over
+    everything the properties that hold whatever the content: vectors within 3 quarter-pels of the full-pel vector, unchanged PUs keep
+    their full-pel SAD, and the stored distortion never grows (a candidate only replaces a strictly larger best)."""
+    pytest.importorskip("torch")
+    cur, ref = _pictures(1920, 1080, "synth")
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    sample = np.random.default_rng(6).choice(desc.shape[0], 12, replace=False)
+    s0 = np.zeros((desc.shape[0], 209), np.uint32); m0 = np.zeros_like(s0)
+    # full-pel results of the whole picture from the device (pinned elsewhere), 209-PU mode
+    import torch
+    dev = torch.device("cuda:0")
+    d_src, d_ref, d_desc = torch.from_numpy(cur.full).to(dev), torch.from_numpy(ref.full).to(dev), torch.from_numpy(desc).to(dev)
+    d_sad = torch.zeros((desc.shape[0], 209), dtype=torch.int32, device=dev); d_mv = torch.zeros_like(d_sad)
+    hip_ctx.fullpel_search209_dev(d_src.data_ptr(), cur.stride, d_ref.data_ptr(), ref.stride, d_desc.data_ptr(), desc.shape[0], 64, 64,
+                                  d_sad.data_ptr(), d_mv.data_ptr())
+    hip_ctx.synchronize()
+    s0, m0 = d_sad.cpu().numpy().view(np.uint32), d_mv.cpu().numpy().view(np.uint32)
+    s_h, m_h = _run_search(hip_ctx, cur, ref, desc, s0, m0, method, True)
+    s_o, m_o, _ = oracle.subpel_refine_method(cur.full, ref.full, desc[sample], s0[sample], m0[sample], method, True)
+    assert np.array_equal(s_h[sample], s_o) and np.array_equal(m_h[sample], m_o)
+    x0 = (m0 & 0xffff).astype(np.int16).astype(np.int32); y0 = (m0 >> 16).astype(np.int16).astype(np.int32)
+    x1 = (m_h & 0xffff).astype(np.int16).astype(np.int32); y1 = (m_h >> 16).astype(np.int16).astype(np.int32)
+    assert (np.abs(x1 - x0) <= 3).all() and (np.abs(y1 - y0) <= 3).all()
+    same = m_h == m0
+    assert np.array_equal(s_h[same], s0[same])
+    assert (s_h <= s0).all()
+    assert (~same).any()
