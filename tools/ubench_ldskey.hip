@@ -4,6 +4,9 @@
 //   0  32 v_qsad + 21 v_lshl_or / v_and_or + 10 v_min3          (today's kernel)
 //   1  32 v_qsad + 6 ds_write_b64 + 21 ds_read_u16_d16_hi + 10 v_min3, reads issued before the v_qsad, waited for after them
 //   2  32 v_qsad + 10 v_min3                                   (lower bound: keys for free)
+//   3  as 1, plus one v_or_b32_e32 per key (what is really needed: the D16 load clears the half that should keep idx)
+//   4  as 0 with every key formed by TWO VOP2 instructions (v_lshlrev_b32 / v_and_b32, then v_or_b32) instead of one VOP3
+//   5  as 4 with every v_min3_u32 replaced by two v_min_u32 (VOP2)
 // Not part of the product.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_ldskey.hip -o gpurun_out/ubench_ldskey
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,9 +55,10 @@ __global__ void __launch_bounds__(256, 4) body(uint32_t* out, uint32_t seed)
 #pragma unroll
     for (int i = 0; i < 10; i++) best[i] = 0xffffffffu;
     uint32_t s = seed * 77u + 13u;
+    uint32_t idxv[4] = {(uint32_t)t, (uint32_t)t + 1u, (uint32_t)t + 2u, (uint32_t)t + 3u};
     for (int it = 0; it < kIter; it++) {
         const uint32_t rd = base + ((it & 1) ? 6 * 2048 : 0), wr = base + ((it & 1) ? 0 : 6 * 2048);
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 3) {
             read_keys(key, rd, std::make_integer_sequence<int, 21>{});
         }
         (void)rd;
@@ -70,13 +74,35 @@ __global__ void __launch_bounds__(256, 4) body(uint32_t* out, uint32_t seed)
                 else asm volatile("v_lshl_or_b32 %0, %1, 16, %0" : "+v"(key[i]) : "v"(a));
             }
         }
-        if (MODE == 1) {
+        if (MODE == 4 || MODE == 5) {
+#pragma unroll
+            for (int i = 0; i < 21; i++) {
+                const uint32_t a = (uint32_t)(acc[i & 7] >> ((i & 8) ? 32 : 0));
+                uint32_t tmp;
+                if (i & 1) asm volatile("v_and_b32_e32 %0, %1, %2" : "=v"(tmp) : "s"(0xffff0000u), "v"(a));
+                else asm volatile("v_lshlrev_b32_e32 %0, 16, %1" : "=v"(tmp) : "v"(a));
+                asm volatile("v_or_b32_e32 %0, %1, %2" : "=v"(key[i]) : "v"(tmp), "v"(idxv[i & 3]));
+            }
+        }
+        if (MODE == 1 || MODE == 3) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             write_accs(acc, wr, std::make_integer_sequence<int, 6>{});
         }
-        (void)wr;
+        if (MODE == 3) {
 #pragma unroll
-        for (int i = 0; i < 10; i++) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(best[i]) : "v"(key[2 * i]), "v"(key[2 * i + 1]));
+            for (int i = 0; i < 21; i++) asm volatile("v_or_b32_e32 %0, %0, %1" : "+v"(key[i]) : "v"(idxv[i & 3]));
+        }
+        (void)wr;
+        if (MODE == 5) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(best[i]) : "v"(key[2 * i]));
+                asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(best[i]) : "v"(key[2 * i + 1]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(best[i]) : "v"(key[2 * i]), "v"(key[2 * i + 1]));
+        }
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < 8; i++) asm volatile("" : "+v"(acc[i]));
@@ -134,12 +160,16 @@ int main()
     HIPCHECK(hipMemcpy(h, d_out, sizeof(h), hipMemcpyDeviceToHost));
     printf("ds_read_u16_d16_hi into 0x00001234 from a cell holding lane number 5: 0x%08x (%s)\n", h[5],
            h[5] == 0x00051234u ? "low half preserved" : "low half NOT preserved");
-    const float t0 = run<0>(d_out, blocks), t1 = run<1>(d_out, blocks), t2 = run<2>(d_out, blocks);
+    const float t0 = run<0>(d_out, blocks), t1 = run<1>(d_out, blocks), t2 = run<2>(d_out, blocks), t3 = run<3>(d_out, blocks), t4 = run<4>(d_out, blocks),
+                t5 = run<5>(d_out, blocks);
     // per wave and loop iteration, in SIMD cycles at 2.4 GHz: a SIMD runs 4 resident waves x 4 rounds
     const double f = 2.4e6 / (16.0 * kIter);
     printf("per loop iteration of one wave (SIMD cycles at 2.4 GHz; 32 v_qsad alone = 517):\n");
     printf("  keys on the VALU (21 v_lshl_or / v_and_or + 10 v_min3): %7.0f   (%.3f ms)\n", t0 * f, t0);
     printf("  keys through LDS (6 ds_write_b64 + 21 ds_read_u16_d16_hi): %7.0f   (%.3f ms)\n", t1 * f, t1);
     printf("  no key formation (10 v_min3 only):                      %7.0f   (%.3f ms)\n", t2 * f, t2);
+    printf("  keys through LDS + one v_or_b32_e32 per key:            %7.0f   (%.3f ms)\n", t3 * f, t3);
+    printf("  keys by two VOP2 each (shift / and, then or):           %7.0f   (%.3f ms)\n", t4 * f, t4);
+    printf("  ... and two v_min_u32 instead of each v_min3_u32:       %7.0f   (%.3f ms)\n", t5 * f, t5);
     return 0;
 }
