@@ -309,3 +309,15 @@ def test_ssd_method_runs_the_same_functions(oracle):
     # and the three methods really are different searches on this content
     s_c, m_c, _ = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 0, True)
     assert (m_c != m_b).any() or (s_c != s_b).any()
+
+
+@pytest.mark.parametrize("all_pu", [False, True])
+def test_refinement_control_flow_480p_all_sbs(oracle, refsubpel, all_pu):
+    """BASELINE config-1 picture size (856x480: partial right column and bottom row), the default 64x64 area, every superblock: the
+    reference's own refinement (SUB_SAD_SEARCH) against the oracle on the full-pel results of the whole picture."""
+    cur, ref = synth.PaPicture(synth.synth_luma(856, 480, 1)), synth.PaPicture(synth.synth_luma(856, 480, 0))
+    desc = svtav1_hip.make_fullpel_desc(cur, ref, None, 64, 64)
+    s0, m0 = (oracle.fullpel_search209_batch if all_pu else oracle.fullpel_search_batch)(cur.full, ref.full, desc)
+    s_r, m_r, d_r = refsubpel.subpel_search(cur.full, ref.full, desc, s0, m0, 0, all_pu)
+    s_o, m_o, d_o = oracle.subpel_refine_method(cur.full, ref.full, desc, s0, m0, 0, all_pu)
+    assert np.array_equal(s_r, s_o) and np.array_equal(m_r, m_o) and np.array_equal(d_r, d_o)
