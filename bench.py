@@ -464,10 +464,11 @@ def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):
     return out
 
 
-def leg_recon_exchange(ctx, torch, dist, svtav1_hip, dev, world, steps=10):
+def leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world, steps=10):
     """The real exchange step of the encode pass (north-star): every rank reconstructs ITS SB-row slab of a picture with the fused TU
-    chain, one RCCL all_gather_into_tensor assembles the luma plane on every rank, then the border padding of PadRefAndSetFlags runs
-    redundantly everywhere.  All ranks take part; times are max over ranks."""
+    chain, then svthip_recon_exchange_dev (C ABI, RCCL over xGMI: one group of direct sends / receives straight into the padded planes
+    of Y, Cb, Cr) assembles the picture on every rank and pads the three planes like PadRefAndSetFlags.  All ranks take part; times are
+    max over ranks.  Everything is enqueued on the context's stream; one host synchronisation per picture."""
     from svtav1_hip import sharded
 
     z = np.load(os.path.join(ROOT, "tests", "golden", "quant_tables.npz"))
@@ -478,7 +479,7 @@ def leg_recon_exchange(ctx, torch, dist, svtav1_hip, dev, world, steps=10):
         wide = bd == 10
         es = 2 if wide else 1
         stride = w + 2 * pad
-        ex = sharded.ReconExchange(w, h, pad)
+        ex = sharded.ReconExchange(w, h, pad, comm=comm, sample_bytes=es)
         y0, nrows = ex.my_rows
         ts = svtav1_hip.TX_SIZES_WH.index((nn, nn))
         types = [0, 3, 9]
@@ -511,18 +512,18 @@ def leg_recon_exchange(ctx, torch, dist, svtav1_hip, dev, world, steps=10):
         recon = torch.zeros_like(pred)
         d_q = torch.empty(max(1, n_tu) * nn * nn, dtype=torch.int32, device=dev)
         d_eob = torch.empty(max(1, n_tu), dtype=torch.int16, device=dev)
-        plane_u8 = recon.view(torch.uint8).view(rows_total, stride * es)
-
-        def pad_fn(_):
-            ctx.pad_plane_dev(recon.data_ptr(), stride, w, h, pad, pad, es)
-            ctx.synchronize()
+        y_u8 = recon.view(torch.uint8).view(rows_total, stride * es)[: h + 2 * pad]
+        # chroma planes (4:2:0, origin 80): carried through the exchange and the padding; their T/Q is not part of this leg
+        c_rows, c_stride = h // 2 + pad, w // 2 + pad
+        chroma = [torch.randint(0, 256, (c_rows, c_stride * es), dtype=torch.uint8, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
 
         def step():
             if n_tu:
                 ctx.encode_tu_batch_dev(src.data_ptr(), pred.data_ptr(), recon.data_ptr(), d_desc.data_ptr(), n_tu, nn, nn, d_qp.data_ptr(),
                                         d_iscan.data_ptr(), None, d_q.data_ptr(), None, d_eob.data_ptr(), None, None, None, wide)
+            ex.exchange([y_u8, chroma[0], chroma[1]])
             ctx.synchronize()
-            ex.exchange(plane_u8[: h + 2 * pad], pad_fn)
 
         for _ in range(2):
             step()
@@ -540,12 +541,14 @@ def leg_recon_exchange(ctx, torch, dist, svtav1_hip, dev, world, steps=10):
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        slab_bytes = max(n for _, n in ex.rows) * stride * es
+        plan = sharded.recon_exchange_plan(ex.picture(1, stride, 1, 1, c_stride), world, ex.rank)
         out[label] = {"ms_per_picture": round(el / steps * 1e3, 4), "slab_rows_per_rank": [n for _, n in ex.rows],
-                      "allgather_bytes_per_rank": slab_bytes if world > 1 else 0, "tus_per_rank_16x16": n_tu,
-                      "collective": "all_gather_into_tensor (RCCL)" if world > 1 else "none (1 rank)"}
-        del src, pred, recon
-    out["workload"] = "per picture: fused TU chain on the rank's SB-row slab -> all-gather of luma slabs -> generate_padding (160 px) on every rank"
+                      "bytes_sent_per_rank": int(sum(x.bytes for x in plan if x.send)), "bytes_received_per_rank": int(sum(x.bytes for x in plan if not x.send)),
+                      "tus_per_rank_16x16": n_tu, "planes": "Y + Cb + Cr",
+                      "exchange": "svthip_recon_exchange_dev: one RCCL group of direct ncclSend/ncclRecv per picture" if world > 1 else "none (1 rank)"}
+        del src, pred, recon, chroma
+    out["workload"] = ("per picture: fused 16x16 TU chain on the rank's luma SB-row slab -> svthip_recon_exchange_dev (slabs of Y, Cb, Cr straight "
+                       "into every rank's padded planes over RCCL) -> generate_padding of the three planes (160 / 80 samples) on every rank")
     return out
 
 
@@ -571,7 +574,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only")
     ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
-    ap.add_argument("--gather-results", action="store_true", help="also all-gather the (sad, mv) results of every step over RCCL")
+    ap.add_argument("--gather-results", action="store_true", help="also gather the (sad, mv) results of every step on every rank (svthip_me_gather_results_dev, RCCL)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -600,6 +603,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     ctx = svtav1_hip.Context(local_rank)
+    comm = sharded.Comm.from_process_group(ctx)      # svthip_comm (RCCL); world 1 never touches RCCL
 
     # ---- headline: frame-sharded hierarchical ME ----
     n_jobs = PICTURES_PER_STEP * world
@@ -621,17 +625,19 @@ def main():
     d_mv = torch.empty((n_blocks, 85), dtype=torch.int32, device=dev)
     params = svtav1_hip.default_me_params(W, H, 3, 0)
     a = (pool.data_ptr(), stride, pool.data_ptr(), stride, d_desc.data_ptr(), n_blocks, SEARCH_W, SEARCH_H, d_sad.data_ptr(), d_mv.data_ptr())
-    counts = [sharded.shard_sb_range(W, H, world, r, "sb")[1] for r in range(world)]
+    if args.gather_results:
+        n_total = sb_all.shape[0]
+        g_sad = torch.empty((n_jobs, n_total, 85), dtype=torch.int32, device=dev)
+        g_mv = torch.empty((n_jobs, n_total, 85), dtype=torch.int32, device=dev)
 
     def step():
         # ONE search-centre launch per 32 pictures over this rank's superblocks (descriptors land in d_desc), then ONE full-pel launch
         if not args.no_hme:
             ctx.hme_search_center_batch_dev(pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_local, None, d_desc.data_ptr())
         ctx.fullpel_search_dev(*a)
-        if args.gather_results and distributed:
-            ctx.synchronize()
-            res = torch.stack([d_sad.view(n_jobs, n_local, 85), d_mv.view(n_jobs, n_local, 85)], dim=-1).permute(1, 0, 2, 3).contiguous()
-            sharded.gather_rows(res, counts)
+        if args.gather_results:   # svthip_me_gather_results_dev on the same stream: every rank ends with all (SAD, MV) rows
+            comm.me_gather_results_dev(d_sad.data_ptr(), g_sad.data_ptr(), n_jobs, n_total, 85 * 4)
+            comm.me_gather_results_dev(d_mv.data_ptr(), g_mv.data_ptr(), n_jobs, n_total, 85 * 4)
 
     def sync():
         ctx.synchronize()
@@ -661,7 +667,7 @@ def main():
 
     legs = {}
     if not args.no_legs:
-        legs["recon_exchange"] = leg_recon_exchange(ctx, torch, dist, svtav1_hip, dev, world)   # every rank takes part
+        legs["recon_exchange"] = leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world)   # every rank takes part
         if rank == 0:
             timer = EventTimer(torch)
             rng = np.random.default_rng(3)

@@ -50,6 +50,21 @@ const char *svthip_last_error(void);
 void *svthip_stream(svthip_ctx *ctx);
 int32_t svthip_synchronize(svthip_ctx *ctx);
 
+/* Pre-size the context-owned device scratch for whole-picture ME calls of up to n_jobs pictures of width x height with n_pu (85 or
+ * 209) PUs per SB, so that no later call allocates (where the reference sizes MeContext_t's buffers once in MeContextCtor,
+ * Codec/EbMotionEstimationContext.c:28-122).  host_forms != 0 also sizes what svthip_motion_estimate_picture (host pointers) needs.
+ * Optional: every entry grows its scratch on demand, stream-ordered (hipMallocAsync / hipFreeAsync on the stream that last used the
+ * context's scratch -- never a device-wide synchronisation under other contexts' work). */
+int32_t svthip_reserve(svthip_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_pu, uint32_t n_jobs, int32_t host_forms);
+
+/* Kernel-selection overrides of ONE context, default 0.  Two entries have a specialised kernel for the common shapes and a general
+ * one for the rest; setting the option routes the common shapes through the general kernel too, which is how the tests cross-check the
+ * two against each other.  Nothing is read from the environment. */
+#define SVTHIP_OPT_SADLOOP_GENERIC 0 /* svthip_sad_loop_batch_dev: one-position-per-lane kernel for every width */
+#define SVTHIP_OPT_CONVOLVE_VALU 1   /* svthip_av1_convolve_*_batch_dev: vector-unit kernel also for sides that are multiples of 32 */
+#define SVTHIP_OPT_COUNT 2
+int32_t svthip_set_option(svthip_ctx *ctx, int32_t option, int32_t value);
+
 /* ---------------------------------------------------------------------------------------------
  * Full-pel 85-PU search of a batch of superblocks against one reference list.
  * Replaces FullPelSearch_LCU + GetEightHorizontalSearchPointResultsAll85PUs + GetSearchPointResults
@@ -190,8 +205,7 @@ int32_t svthip_me_subpel_refine_dev(svthip_ctx *ctx, const uint8_t *d_src_plane,
  *   SSD_SEARCH      : what MotionEstimateLcu hard-wires (:6254) and the two entries above / below compute.
  * The statements around the distortion -- candidate order, strict '<', direction choice, valid quarter-pel positions, buffer selection --
  * are shared by the three methods; with the SAD methods the reference's own HalfPelSearch_LCU + QuarterPelSearch_LCU can be executed in the
- * build container (no NASM-only symbol is reached) and this entry is checked against them.  (The per-PU-tile kernels that
- * SVTHIP_SUBPEL_TILES=1 selects for A/B runs implement SSD_SEARCH only and return SVTHIP_ERR_BAD_PARAMETER for the SAD methods.) */
+ * build container (no NASM-only symbol is reached) and this entry is checked against them. */
 #define SVTHIP_FRACTIONAL_SUB_SAD_SEARCH 0
 #define SVTHIP_FRACTIONAL_FULL_SAD_SEARCH 1
 #define SVTHIP_FRACTIONAL_SSD_SEARCH 2
@@ -659,6 +673,72 @@ int32_t svthip_open_loop_intra_search_batch_dev(svthip_ctx *ctx, const uint8_t *
 int32_t svthip_open_loop_intra_search_picture(svthip_ctx *ctx, const svthip_host_picture *cur, const svthip_ois_params *params,
                                               const void *const *me_results, uint32_t n_pu, uint32_t *cand, uint8_t *total);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: superblocks of a picture sharded over the GPUs of one node, RCCL over xGMI for the one real exchange.
+ * One rank per GPU -- a thread of the reference's single process (its ME / EncDec threads already own one context each) or one
+ * process per GPU.  Every rank holds the read-only source planes, so ME needs NO data-path collective; the encode pass's T/Q shards by
+ * SB-row slab, and the reconstructed slabs are exchanged so that every rank holds the whole padded reference picture for the next
+ * picture's inter prediction -- what PadRefAndSetFlags (Codec/EbEncDecProcess.c:1135-1204, called :1852) finishes on one host.
+ *
+ * Partition (pure host arithmetic, callable without a device):
+ *   svthip_shard_range     : contiguous share of n_units (superblocks for ME, balanced to ONE unit: 1080p = 510 SBs -> 64/64/64/64/64/64/63/63)
+ *   svthip_recon_slab_rows : luma rows [first_row, first_row + n_rows) of rank's SB-row slab (1080p = 17 SB rows -> 3/2/2/2/2/2/2/2 rows of 64)
+ * Plans: the byte ranges a rank sends / receives, as the device entries below will issue them; a test (or another transport) can
+ * execute the same list.  offset / bytes are relative to the plane (`plane` 0 = Y, 1 = Cb, 2 = Cr) resp. to d_full / d_local (`plane` = job). */
+typedef struct svthip_comm svthip_comm;
+#define SVTHIP_COMM_ID_BYTES 128 /* ncclUniqueId */
+
+void svthip_shard_range(uint32_t n_units, int32_t world, int32_t rank, uint32_t *first, uint32_t *count);
+void svthip_recon_slab_rows(uint32_t height, int32_t world, int32_t rank, uint32_t *first_row, uint32_t *n_rows);
+
+/* The planes of an EbPictureBufferDesc_t reference picture (EbReferenceObject_t::referencePicture / referencePicture16bit) on the
+ * device: pointers to the first sample of the PADDED planes; luma origin (origin_x, origin_y), chroma (4:2:0) origin, size and
+ * slab rows are the luma values >> 1 exactly as PadRefAndSetFlags passes them.  cb == cr == NULL: luma only. */
+typedef struct svthip_recon_picture {
+    void *y, *cb, *cr;
+    uint32_t stride_y, stride_cb, stride_cr; /* samples */
+    uint16_t width, height;                  /* luma, even */
+    uint16_t origin_x, origin_y;             /* luma padding (the reference allocates 160 + for reference pictures, Codec/EbEncHandle.c) */
+    uint8_t sample_bytes;                    /* 1: 8-bit planes, 2: 16-bit planes */
+    uint8_t reserved[3];
+} svthip_recon_picture;
+
+typedef struct svthip_xfer {
+    int32_t peer;
+    uint32_t plane;
+    uint32_t send; /* 1: this rank -> peer, 0: peer -> this rank */
+    uint64_t offset, bytes;
+} svthip_xfer;
+
+/* n_xfers receives the number of transfers; out may be NULL to query it. */
+int32_t svthip_recon_exchange_plan(const svthip_recon_picture *pic, int32_t world, int32_t rank, svthip_xfer *out, uint32_t max_xfers,
+                                   uint32_t *n_xfers);
+int32_t svthip_me_gather_plan(uint32_t n_sb_total, uint32_t n_jobs, uint32_t record_bytes, int32_t world, int32_t rank, svthip_xfer *out,
+                              uint32_t max_xfers, uint32_t *n_xfers);
+
+/* Communicator of one rank, bound to the context whose device it uses.  Rank 0 calls svthip_comm_get_unique_id and hands the 128 bytes
+ * to the other ranks by whatever the host has (shared memory between the reference's threads; a file, socket or launcher store between
+ * processes); every rank then calls svthip_comm_create (collective: ncclCommInitRank).  world == 1 needs no id and never touches RCCL. */
+int32_t svthip_comm_get_unique_id(uint8_t *id /* [SVTHIP_COMM_ID_BYTES] */);
+int32_t svthip_comm_create(svthip_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world, svthip_comm **out);
+void svthip_comm_destroy(svthip_comm *comm);
+int32_t svthip_comm_rank(const svthip_comm *comm);
+int32_t svthip_comm_world(const svthip_comm *comm);
+const char *svthip_comm_last_error(void);
+
+/* Reconstructed-picture exchange + PadRefAndSetFlags.  On entry every rank's planes hold ITS slab (svthip_recon_slab_rows; chroma rows
+ * >> 1) reconstructed in place; on return (stream-ordered, no host synchronisation) every rank's planes hold the whole picture with
+ * its borders replicated (generate_padding / generate_padding16_bit of Y, Cb, Cr, Codec/EbMcp.c:173-262).  xGMI is a point-to-point
+ * mesh, so the exchange is ONE RCCL group of direct sends / receives: each slab goes over its own link straight into its place in the
+ * peer's plane (whole rows, side borders included -- they are rewritten by the padding), no staging buffer. */
+int32_t svthip_recon_exchange_dev(svthip_comm *comm, const svthip_recon_picture *pic, void *stream);
+
+/* ME results of a frame-sharded search on every rank (for a consumer that needs all of me_results everywhere; the ME itself needs no
+ * exchange): d_local = this rank's [n_jobs][count][record_bytes] (count from svthip_shard_range(n_sb_total, ..)), d_full =
+ * [n_jobs][n_sb_total][record_bytes] on every rank.  record_bytes = n_pu * sizeof(svthip_me_cu_result). */
+int32_t svthip_me_gather_results_dev(svthip_comm *comm, const void *d_local, void *d_full, uint32_t n_jobs, uint32_t n_sb_total,
+                                     uint32_t record_bytes, void *stream);
 
 /* Launch-duration probe for bench.py: runs the same launch `iters` times on the context stream between
  * two HIP events and returns the average kernel time in milliseconds (inputs are device pointers). */

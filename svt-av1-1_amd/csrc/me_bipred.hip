@@ -1,24 +1,17 @@
-// svt-av1-1_amd/csrc/me_subpel.hip
+// svt-av1-1_amd/csrc/me_bipred.hip
 //
-// Half-pel + quarter-pel refinement of the 85 square PUs of a batch of superblocks against one list, gfx950.
-// Replaces InterpolateSearchRegionAVC (Source/Lib/Codec/EbMotionEstimation.c:1707-1835), HalfPelSearch_LCU /
-// PU_HalfPelRefinement (:2246-2786 / :1842-2240) and QuarterPelSearch_LCU / SetQuarterPelRefinementInputsOnTheFly /
-// PU_QuarterPelRefinementOnTheFly / CombinedAveragingSSD (:3337-4114 / :3246-3331 / :2824-3239 / :2792-2817) in the
-// configuration MotionEstimateLcu uses for enc modes M0/M1: SSD_SEARCH metric, every PU size refined,
-// fractional_search64x64 on, quarter-pel on.
+// Bi-prediction search and result packing of MotionEstimateLcu's tail (Source/Lib/Codec/EbMotionEstimation.c:6973-7146):
+// BiPredictionSearch / BiPredictionCompensation / BiPredAverging / SelectBuffer / QuarterPelCompensation (:5261-5342, :5090-5254,
+// :4933-5081, :4762-4920) and the Sort3Elements-ordered fill of me_results[sb][pu] (:7047-7143), gfx950.
 //
-// The reference interpolates three whole planes (b, h, j) over the search region (~3 x 17 k samples) and then
-// reads 9 + <=3 blocks per PU from them.  Here the planes are never materialised: the integer window
-// ((sw+71) x (sh+71) bytes) is staged once in LDS and each wave computes, per PU, only the (W+4) x (H+4)
-// tiles of b, h, j it can touch.  b[x,y] = half-pel (x-1/2, y), h[x,y] = (x, y-1/2), j[x,y] = vertical filter of
-// the ROUNDED b plane at (x-1/2, y-1/2): {-2,18,18,-2}, +16 >> 5, clip -- identical arithmetic, including the
-// double rounding of j, the 8-bit-wrapped SSD of the half-pel stage, the true SSD of the quarter-pel stage, the
-// L,R,T,B,TL,TR,BR,BL evaluation order with strict '<', and the 64x64 PU being quarter-pel refined on a 32x32 block.
-//
-// One 256-thread workgroup per (SB, list); wave 0 refines the 64x64 PU, wave 1 the four 32x32, wave 2 the sixteen
-// 16x16, wave 3 the sixty-four 8x8 (equal pixel area per wave).  Small PUs are refined several at a time by lane groups
-// (16 lanes per 16x16 PU -> 4 PUs per pass, 8 lanes per 8x8 PU -> 8 PUs per pass), each group with its own tiles, so a wave
-// pays the LDS round trips and the (group-wide) reductions once per pass instead of once per PU.
+// Two forms:
+//  * bipred_stored_pack_kernel -- the whole-picture chains with sub-pel on: subpel_planes_kernel (me_subpel_planes.hip) has stored every PU's
+//    prediction at its refined vector, so a PU's bi-prediction SAD is SAD(src, avg(P0, P1)) of two stored blocks;
+//  * bipred_pack_kernel / bipred_nsq_pack_kernel -- the stand-alone entries (any vectors, sub-pel off included): the integer windows of both
+//    lists are staged in LDS and each lane group interpolates only the (W+4) x (H+4) tiles of b, h, j its PU's vector can touch.
+//    b[x,y] = half-pel (x-1/2, y), h[x,y] = (x, y-1/2), j[x,y] = vertical filter of the ROUNDED b plane at (x-1/2, y-1/2):
+//    {-2,18,18,-2}, +16 >> 5, clip -- the reference's arithmetic including the double rounding of j.
+//    Wave roles: 0 = 64x64, 1 = 32x32s, 2 = 16x16s (16 lanes per PU), 3 = 8x8s (8 lanes per PU); the 209-PU kernel has five roles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -103,129 +96,6 @@ __device__ void fill_tiles(const Win& win, T& t, int bx, int by, int l)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// One PU (PW x PH pixels at (px,py) in the SB; tiles T at least that large) per group of LPP consecutive lanes, l = lane
-// within the group.  All lanes of a group return the same updated sad / mv / ssd / dir.
-template <int PW, int PH, class T, int LPP>
-__device__ void half_pel_pu(const lds_u8* src, const Win& win, const T& t, int px, int py, int bx, int by,
-                            int x_mv, int y_mv, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int& dir)
-{
-    // candidate k: plane, dx, dy  (L, R, T, B, TL, TR, BR, BL)
-    uint32_t ssd[9], sad[8];
-#pragma unroll
-    for (int k = 0; k < 9; k++) ssd[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) sad[k] = 0;
-    constexpr int TW = T::TW, PW4 = PW / 4;
-#pragma unroll 2
-    for (int i = l; i < PW4 * PH; i += LPP) {  // 4 pixels per step
-        const int y = i / PW4, x = 4 * (i - y * PW4);
-        const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
-        // tile samples of pixel x sit at tile column x + 2: rows are 4-byte aligned, so L / R candidates are the two
-        // aligned dwords at column x shifted by 2 / 3 bytes
-        const lds_u32* bq = reinterpret_cast<const lds_u32*>(t.bt + (y + 4) * TW + x);
-        const lds_u32* hq = reinterpret_cast<const lds_u32*>(t.ht + (y + 2) * TW + x);
-        const lds_u32* jq = reinterpret_cast<const lds_u32*>(t.jt + (y + 2) * TW + x);
-        const uint32_t b0 = bq[0], b1 = bq[1], h0 = hq[0], h1 = hq[1], h2 = hq[TW / 4], h3 = hq[TW / 4 + 1];
-        const uint32_t j0 = jq[0], j1 = jq[1], j2 = jq[TW / 4], j3 = jq[TW / 4 + 1];
-        const uint32_t c[8] = {__builtin_amdgcn_alignbyte(b1, b0, 2), __builtin_amdgcn_alignbyte(b1, b0, 3),
-                               __builtin_amdgcn_alignbyte(h1, h0, 2), __builtin_amdgcn_alignbyte(h3, h2, 2),
-                               __builtin_amdgcn_alignbyte(j1, j0, 2), __builtin_amdgcn_alignbyte(j1, j0, 3),
-                               __builtin_amdgcn_alignbyte(j3, j2, 3), __builtin_amdgcn_alignbyte(j3, j2, 2)};
-        // The reference picks the SSD leaf by WIDTH only (SpatialFullDistortionKernel_funcPtrArray[asm][Log2f(pu_width) - 2], :1912) and
-        // the width-8 leaf always runs 8 rows whatever pu_height is (ASM_SSE4_1/EbPictureOperators_Intrinsic_SSE4_1.c:534-571): 8x16 and
-        // 8x32 PUs are compared on their top 8 rows.  The stored SAD (NxMSadKernel, :1943) covers every row.
-        const bool in_ssd = (PW != 8) || (y < 8);
-        if (in_ssd) ssd[8] = wssd4(s4, lds_u32_at(win.p + (by + y + kMargin) * win.pitch + bx + x + kMargin), ssd[8]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (in_ssd) ssd[k] = wssd4(s4, c[k], ssd[k]);
-            sad[k] = __builtin_amdgcn_sad_u8(s4, c[k], sad[k]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; k++) ssd[k] = gsum<LPP>(ssd[k]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) sad[k] = gsum<LPP>(sad[k]);
-    best_ssd = ssd[8];  // SSD of the best full-pel candidate (:1912)
-    const int mvdx[8] = {-2, 2, 0, 0, -2, 2, 2, -2}, mvdy[8] = {0, 0, -2, 2, -2, -2, 2, 2};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (ssd[k] < best_ssd) {  // strict '<' (:1942)
-            best_sad = sad[k];
-            best_mv = ((uint32_t)(uint16_t)(y_mv + mvdy[k]) << 16) | (uint32_t)(uint16_t)(x_mv + mvdx[k]);
-            best_ssd = ssd[k];
-        }
-    }
-    uint32_t m = ssd[0];
-#pragma unroll
-    for (int k = 1; k < 8; k++) m = ssd[k] < m ? ssd[k] : m;
-    // first match in the order L, R, T, B, TL, TR, BL, BR (:2209-2238)
-    dir = (m == ssd[0]) ? DIR_L : (m == ssd[1]) ? DIR_R : (m == ssd[2]) ? DIR_T : (m == ssd[3]) ? DIR_B
-        : (m == ssd[4]) ? DIR_TL : (m == ssd[5]) ? DIR_TR : (m == ssd[7]) ? DIR_BL : DIR_BR;
-}
-
-template <int PW, int PH, class T, int LPP>
-__device__ void quarter_pel_pu(const lds_u8* src, const Win& win, const T& t, int px, int py, int bx, int by, int xo,
-                               int yo, int l, uint32_t& best_sad, uint32_t& best_mv, uint32_t& best_ssd, int d)
-{
-    const int x_mv = (int)(int16_t)(best_mv & 0xffffu), y_mv = (int)(int16_t)(best_mv >> 16);
-    const int xs = ((x_mv + 2) >> 2) - xo + px, ys = ((y_mv + 2) >> 2) - yo + py;  // :2847-2848 (+ PU offset)
-    const int method = (y_mv & 2) + ((x_mv & 2) >> 1);
-    bool valid[8];  // L, R, T, B, TL, TR, BR, BL
-    if (method) {
-        valid[4] = (d == DIR_R || d == DIR_BR || d == DIR_B);
-        valid[2] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
-        valid[5] = (d == DIR_B || d == DIR_BL || d == DIR_L);
-        valid[1] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
-        valid[6] = (d == DIR_L || d == DIR_TL || d == DIR_T);
-        valid[3] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
-        valid[7] = (d == DIR_T || d == DIR_TR || d == DIR_R);
-        valid[0] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
-    } else {
-        valid[4] = (d == DIR_L || d == DIR_TL || d == DIR_T);
-        valid[2] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
-        valid[5] = (d == DIR_T || d == DIR_TR || d == DIR_R);
-        valid[1] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
-        valid[6] = (d == DIR_R || d == DIR_BR || d == DIR_B);
-        valid[3] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
-        valid[7] = (d == DIR_B || d == DIR_BL || d == DIR_L);
-        valid[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
-    }
-    // every direction enables exactly three of the eight positions; each lane group walks ITS three in ascending order (the
-    // reference's evaluation order), so all groups of a wave run three passes whatever their directions are
-    uint32_t vmask = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) vmask |= valid[k] ? (1u << k) : 0u;
-#pragma unroll 1
-    for (int pass = 0; pass < 3; pass++) {
-        const int k = __builtin_ctz(vmask);  // lowest remaining position of this group
-        vmask &= vmask - 1;
-        const int q1 = kQuarter[method][k][0], q2 = kQuarter[method][k][1];
-        const int p1 = q1 & 3, dx1 = ((q1 >> 2) & 3) - 1, dy1 = ((q1 >> 4) & 3) - 1;
-        const int p2 = q2 & 3, dx2 = ((q2 >> 2) & 3) - 1, dy2 = ((q2 >> 4) & 3) - 1;
-        // L, R, T, B, TL, TR, BR, BL: dx = {-1, 1, 0, 0, -1, 1, 1, -1}, dy = {0, 0, -1, 1, -1, -1, 1, 1}, two bits each (+1)
-        const int qdx = (int)((0x2858u >> (2 * k)) & 3u) - 1, qdy = (int)((0xA085u >> (2 * k)) & 3u) - 1;
-        uint32_t ssd = 0, sad = 0;
-#pragma unroll 2
-        for (int i = l; i < (PW / 4) * PH; i += LPP) {  // 4 pixels per step
-            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            const uint32_t s4 = *reinterpret_cast<const lds_u32*>(src + (py + y) * 64 + px + x);
-            const uint32_t a = plane_sample4(win, t, p1, xs + x + dx1, ys + y + dy1, bx, by);
-            const uint32_t b = plane_sample4(win, t, p2, xs + x + dx2, ys + y + dy2, bx, by);
-            const uint32_t v = avg_u8x4(a, b);
-            ssd = ssd4(s4, v, ssd);  // CombinedAveragingSSD: true SSD (:2792-2817)
-            sad = __builtin_amdgcn_sad_u8(s4, v, sad);
-        }
-        ssd = gsum<LPP>(ssd);
-        sad = gsum<LPP>(sad);
-        if (ssd < best_ssd) {
-            best_sad = sad;
-            best_mv = ((uint32_t)(uint16_t)(y_mv + qdy) << 16) | (uint32_t)(uint16_t)(x_mv + qdx);
-            best_ssd = ssd;
-        }
-    }
-}
-
 template <class T>
 __device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const T& t, int e0, int e1, int x, int y, int bx, int by)
 {
@@ -234,131 +104,7 @@ __device__ __forceinline__ uint32_t bipred_sample4(const Win& win, const T& t, i
     return avg_u8x4(a, b);
 }
 
-// half + quarter for one PW x PH PU at (px,py) per lane group; `pu` = ME-buffer index (group-uniform)
-template <int PW, int PH, int LPP>
-__device__ void refine_pu(const lds_u8* src, const Win& win, Tiles<PW, PH>& t, int px, int py, int xo, int yo, int l,
-                          uint32_t* sad_io, uint32_t* mv_io, int pu, uint32_t* pred_out = nullptr)
-{
-    uint32_t bs = sad_io[pu], bm = mv_io[pu], bssd = 0;
-    const int x_mv = (int)(int16_t)(bm & 0xffffu), y_mv = (int)(int16_t)(bm >> 16);
-    const int bx = (x_mv >> 2) - xo + px, by = (y_mv >> 2) - yo + py;
-    fill_tiles<Tiles<PW, PH>, LPP>(win, t, bx, by, l);
-    int dir = 0;
-    half_pel_pu<PW, PH, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, x_mv, y_mv, l, bs, bm, bssd, dir);
-    if (PW == 64 && PH == 64)  // the 64x64 PU is quarter-pel refined on a 32x32 block at the SB origin (:3395-3409)
-        quarter_pel_pu<32, 32, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
-    else
-        quarter_pel_pu<PW, PH, Tiles<PW, PH>, LPP>(src, win, t, px, py, bx, by, xo, yo, l, bs, bm, bssd, dir);
-    if (l == 0) {
-        sad_io[pu] = bs;
-        mv_io[pu] = bm;
-    }
-    if (pred_out) {
-        // the prediction block at the refined MV, as BiPredictionCompensation would build it (kBiFrac): the bi-prediction stage
-        // then averages two stored blocks instead of interpolating both lists again.  floor(mv / 4) is the full-pel position or
-        // one sample left / above it, so the tiles of this PU cover every sample the table can ask for.
-        const int fx = (int)(int16_t)(bm & 0xffffu), fy = (int)(int16_t)(bm >> 16);
-        const int f = (fx & 3) + ((fy & 3) << 2);
-        const int e0 = kBiFrac[f][0], e1 = kBiFrac[f][1];
-        const int ix = (fx >> 2) - xo + px, iy = (fy >> 2) - yo + py;
-#pragma unroll 2
-        for (int i = l; i < (PW / 4) * PH; i += LPP) {
-            const int y = i / (PW / 4), x = 4 * (i - y * (PW / 4));
-            pred_out[i] = bipred_sample4(win, t, e0, e1, ix + x, iy + y, bx, by);
-        }
-    }
-}
-
 }  // namespace
-
-__global__ void __launch_bounds__(256) subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
-                                                       const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
-                                                       const int32_t* __restrict__ desc, int disable_8x8, int pu_stride,
-                                                       uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv,
-                                                       uint32_t* __restrict__ pred_out, int pred_slots)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    // role of this wave: 0 = 64x64, 1 = 32x32s, 2 = 16x16s, 3 = 8x8s.  The roles differ in work (the 8x8 wave fills twice the
-    // tile samples of the 64x64 wave) and wave k of every workgroup lands on SIMD k, so the assignment rotates with the
-    // workgroup index to even out the four SIMDs of a CU.
-    const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) & 3);
-    const int32_t* d = desc + 6 * blockIdx.x;
-    const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
-
-    // LDS: [src 64x64][tiles 64 | 32 | 16 | 8][window]
-    lds_u8* src_lds = (lds_u8*)smem;
-    lds_u8* tile_base = src_lds + 4096;
-    constexpr int t64 = Tiles<64>::bytes, t32 = Tiles<32>::bytes, t16 = Tiles<16>::bytes, t8 = Tiles<8>::bytes;
-    lds_u8* wbuf = tile_base + kTileBytes;
-    const int wcols = sw + 63 + 2 * kMargin;
-    const int wrows = sh + 63 + 2 * kMargin;
-    const int pitch = (wcols + 3) & ~3;
-
-    // stage the source SB and the integer window (search position (0,0) at [kMargin][kMargin])
-    for (int i = tid; i < 64 * 16; i += 256) {
-        const int r = i >> 4, c = i & 15;
-        reinterpret_cast<lds_u32*>(src_lds)[i] =
-            *reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)r * src_stride + 4 * c);
-    }
-    {
-        const uint8_t* base = ref_plane + ref_off - (size_t)kMargin * ref_stride - kMargin;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(base);
-        const uint32_t shf = (uint32_t)(a0 & 3u);
-        const __attribute__((address_space(1))) uint32_t* base4 = (const __attribute__((address_space(1))) uint32_t*)(a0 & ~(uintptr_t)3);  // global, not generic
-        const int ndw = pitch >> 2, rstride4 = ref_stride >> 2;
-        const int total = wrows * ndw;
-        const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;
-        for (int i = tid; i < total; i += 256) {
-            const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
-            const __attribute__((address_space(1))) uint32_t* p = base4 + (size_t)r * rstride4 + c;
-            reinterpret_cast<lds_u32*>(wbuf)[i] = __builtin_amdgcn_alignbyte(p[1], p[0], shf);
-        }
-    }
-    __syncthreads();
-
-    Win win{wbuf, pitch};
-    uint32_t* sad_io = io_sad + (size_t)pu_stride * blockIdx.x;  // [n_sb][pu_stride], the squares are entries 0..84
-    uint32_t* mv_io = io_mv + (size_t)pu_stride * blockIdx.x;
-    // optional prediction store: [n_sb][pred_slots][1024 dwords], slot 0 = 64x64, 1 = 32x32, 2 = 16x16, 3 = 8x8, PUs in raster order
-    uint32_t* pred = pred_out ? pred_out + (size_t)blockIdx.x * pred_slots * 1024 : nullptr;
-
-    if (wave == 0) {
-        Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-        refine_pu<64, 64, 64>(src_lds, win, t, 0, 0, xo, yo, lane, sad_io, mv_io, 0, pred);
-    } else if (wave == 1) {
-        lds_u8* b = tile_base + t64;
-        Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
-        for (int p = 0; p < 4; p++)
-            refine_pu<32, 32, 64>(src_lds, win, t, (p & 1) << 5, (p >> 1) << 5, xo, yo, lane, sad_io, mv_io, 1 + p,
-                                  pred ? pred + 1024 + p * 256 : nullptr);
-    } else if (wave == 2) {
-        lds_u8* b = tile_base + t64 + t32 + (lane >> 4) * t16;  // 4 PUs per pass, 16 lanes each
-        Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
-        for (int pass = 0; pass < 4; pass++) {
-            const int p = pass * 4 + (lane >> 4);
-            refine_pu<16, 16, 16>(src_lds, win, t, (p & 3) << 4, (p >> 2) << 4, xo, yo, lane & 15, sad_io, mv_io, 5 + kTab16[p],
-                                  pred ? pred + 2048 + p * 64 : nullptr);
-        }
-    } else if (!disable_8x8) {
-        lds_u8* b = tile_base + t64 + t32 + kGroups16 * t16 + (lane >> 3) * t8;  // 8 PUs per pass, 8 lanes each
-        Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
-        for (int pass = 0; pass < 8; pass++) {
-            const int p = pass * 8 + (lane >> 3);
-            refine_pu<8, 8, 8>(src_lds, win, t, (p & 7) << 3, (p >> 3) << 3, xo, yo, lane & 7, sad_io, mv_io, 21 + kTab8[p],
-                               pred ? pred + 3072 + p * 16 : nullptr);
-        }
-    } else if (pred) {
-        // cu8x8_mode 1: the 8x8 PUs keep their full-pel MVs; the 209-PU mode still bi-predicts them, from the integer samples
-        for (int i = lane; i < 1024; i += 64) {
-            const int p = i >> 4, y = (i >> 1) & 7, x = (i & 1) * 4;
-            const uint32_t m = mv_io[21 + kTab8[p]];
-            const int ix = ((int)(int16_t)(m & 0xffffu) >> 2) - xo + ((p & 7) << 3) + x, iy = ((int)(int16_t)(m >> 16) >> 2) - yo + ((p >> 3) << 3) + y;
-            pred[3072 + i] = lds_u32_at(win.p + (iy + kMargin) * win.pitch + ix + kMargin);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Bi-prediction SAD + result packing (Codec/EbMotionEstimation.c:6973-7146).
 // ------------------------------------------------------------------------------------------------------------
@@ -434,21 +180,6 @@ __device__ constexpr int kNsqTileOff[kNsqRoles + 1] = {0, kNsqTile[0], kNsqTile[
                                             kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3],
                                             (kNsqTile[0] + kNsqTile[1] + kNsqTile[2] + kNsqTile[3] + kNsqTile[4] + 15) & ~15};
 __device__ constexpr int kNsqPredOff[kNsqRoles + 1] = {0, 2048, 4096, 5120, 6144, 7168};  // list-0 predictions: PUs per pass x PW x PH bytes
-
-// sub-pel refinement of the `count` PUs of one shape class starting at raster PU index `base`, 64 / LPP of them per pass
-template <int PW, int PH, int LPP>
-__device__ void refine_class(const lds_u8* src, const Win& win, lds_u8* tiles, int xo, int yo, int lane, uint32_t* sad_io, uint32_t* mv_io,
-                             int base, int count, uint32_t* pred)  // pred: this class' 1024-dword prediction slot, or null
-{
-    constexpr int G = 64 / LPP;
-    const int g = lane / LPP, l = lane % LPP;
-    Tiles<PW, PH> t = Tiles<PW, PH>::at(tiles + g * Tiles<PW, PH>::bytes);
-#pragma unroll 1
-    for (int p = g; p < count; p += G) {
-        const int pu = base + p;
-        refine_pu<PW, PH, LPP>(src, win, t, kPu.px[pu], kPu.py[pu], xo, yo, l, sad_io, mv_io, kPu.me[pu], pred ? pred + p * (PW * PH / 4) : nullptr);
-    }
-}
 
 // bi-prediction SADs of one shape class into bisad[] (ME-buffer index)
 template <int PW, int PH, int LPP>
@@ -563,59 +294,6 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
         if (n_lists == 2 && (bipred_8x8 || pu < 21)) total = 3;
         out[85 * sb + pu] = pack_result(s0[n], m0[n], n_lists == 2 ? s1[n] : 0u, m1[n], total == 3 ? bisad[n] : 0u, n_lists, total);
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// 209-PU mode: sub-pel refinement of the 124 rectangular PUs (HalfPelSearch_LCU :2418-2786, QuarterPelSearch_LCU
-// :3580-4114).  io arrays are [n_sb][209] in ME-buffer order; the squares (entries 0..84) are refined by subpel85_kernel.
-// One 320-thread workgroup per (SB, list), wave role = (wave + SB) mod 5.
-// ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(320) subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
-                                                         const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
-                                                         const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
-                                                         uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int role = __builtin_amdgcn_readfirstlane(((tid >> 6) + (int)blockIdx.x) % kNsqRoles);
-    const int32_t* d = desc + 6 * blockIdx.x;
-    const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
-    // LDS: [src 64x64][tiles of the five roles][window]
-    lds_u8* src_lds = (lds_u8*)smem;
-    lds_u8* tile_base = src_lds + 4096;
-    lds_u8* wbuf = tile_base + kNsqTileOff[kNsqRoles];
-    const int pitch = (sw + 63 + 2 * kMargin + 3) & ~3;
-    for (int i = tid; i < 64 * 16; i += 320) {
-        const int r = i >> 4, c = i & 15;
-        reinterpret_cast<lds_u32*>(src_lds)[i] = *reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)r * src_stride + 4 * c);
-    }
-    stage_window(wbuf, pitch, sh + 63 + 2 * kMargin, ref_plane, ref_off, ref_stride, tid, 320);
-    __syncthreads();
-    Win win{wbuf, pitch};
-    uint32_t* sad_io = io_sad + (size_t)209 * blockIdx.x;
-    uint32_t* mv_io = io_mv + (size_t)209 * blockIdx.x;
-    lds_u8* tiles = tile_base + kNsqTileOff[role];
-    // optional prediction store: [n_sb][14 slots][1024 dwords]; slots 4..13 = the rectangular classes in ME-buffer order
-    // (64x32, 32x16, 16x8, 32x64, 16x32, 8x16, 32x8, 8x32, 64x16, 16x64), PUs in raster order inside a slot
-    uint32_t* pred = pred_out ? pred_out + (size_t)blockIdx.x * 14 * 1024 : nullptr;
-#define SLOT(k) (pred ? pred + (k) * 1024 : nullptr)
-    if (role == 0) {
-        refine_class<16, 8, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 95, 32, SLOT(6));
-        refine_class<32, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 127, 2, SLOT(7));
-    } else if (role == 1) {
-        refine_class<8, 16, 8>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 137, 32, SLOT(9));
-        refine_class<64, 32, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 85, 2, SLOT(4));
-    } else if (role == 2) {
-        refine_class<32, 8, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 169, 16, SLOT(10));
-        refine_class<16, 64, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 205, 4, SLOT(13));
-    } else if (role == 3) {
-        refine_class<8, 32, 16>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 185, 16, SLOT(11));
-        refine_class<64, 16, 64>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 201, 4, SLOT(12));
-    } else {
-        refine_class<32, 16, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 87, 8, SLOT(5));
-        refine_class<16, 32, 32>(src_lds, win, tiles, xo, yo, lane, sad_io, mv_io, 129, 8, SLOT(8));
-    }
-#undef SLOT
 }
 
 // 209-PU mode: bi-prediction SADs of the rectangular PUs, then packing of all 209 PUs (:6973-7146; in this mode every PU
@@ -775,17 +453,8 @@ size_t bipred_lds_bytes(uint32_t max_sw, uint32_t max_sh)
     return 4096 + kPredBytes + kTileBytes + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
 }
 
-size_t subpel_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh) { return 4096 + kNsqTileOff[kNsqRoles] + subpel_window_bytes(max_sw, max_sh) + 16; }
-
 size_t bipred_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
     return 4096 + kNsqPredOff[kNsqRoles] + kNsqTileOff[kNsqRoles] + 2 * subpel_window_bytes(max_sw, max_sh) + 16;
 }
-
-size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh)
-{
-    const size_t pitch = (max_sw + 63 + 2 * kMargin + 3) & ~(size_t)3;
-    return 4096 + kTileBytes + pitch * (max_sh + 63 + 2 * kMargin) + 16;
-}
-
 }  // namespace svthip

@@ -54,24 +54,15 @@ __global__ void ois_kernel(const uint8_t* __restrict__ pool, PaJobTable jobs, sv
                            uint32_t* __restrict__ out_cand, uint8_t* __restrict__ out_total);
 hipError_t launch_pad_plane(void* plane, uint32_t stride, int width, int height, int pad_w, int pad_h, int sample_bytes, hipStream_t s);
 
-__global__ void subpel85_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
-                                const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* __restrict__ desc,
-                                int disable_8x8, int pu_stride, uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv,
-                                uint32_t* __restrict__ pred_out, int pred_slots);
-size_t subpel_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                      uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
                                      uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out, int method);
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh);
-__global__ void subpel_nsq_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
-                                  uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t* __restrict__ io_sad,
-                                  uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out);
 __global__ void bipred_stored_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const int32_t* __restrict__ desc0,
                                           const uint8_t* __restrict__ pred0, const uint8_t* __restrict__ pred1,
                                           const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,
                                           const uint32_t* __restrict__ sad1, const uint32_t* __restrict__ mv1, int n_pu, int bipred_8x8,
                                           svthip_me_cu_result* __restrict__ out);
-size_t subpel_nsq_lds_bytes(uint32_t max_sw, uint32_t max_sh);
 __global__ void bipred_nsq_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                        const uint8_t* __restrict__ ref0_plane, uint32_t ref0_stride, const int32_t* __restrict__ desc0,
                                        const uint8_t* __restrict__ ref1_plane, uint32_t ref1_stride, const int32_t* __restrict__ desc1,

@@ -42,6 +42,10 @@ struct svthip_ctx {
     // the stream the context-owned scratch was last used on, and an event to order a different stream behind it
     hipStream_t scratch_stream;
     hipEvent_t scratch_event;
+    // kernel-selection overrides (svthip_set_option): per context, never read from the environment
+    int32_t opt[SVTHIP_OPT_COUNT];
+    // geometry the SB-origin table in slot 9 was last built for (host-pointer picture forms)
+    uint32_t sb_table_w, sb_table_h;
 };
 
 namespace {
@@ -55,7 +59,6 @@ hipError_t g_attr_status[16];
 void set_kernel_attrs(int device)
 {
     const void* kernels[] = {reinterpret_cast<const void*>(svthip::fullpel85_kernel),  reinterpret_cast<const void*>(svthip::fullpel209_kernel),
-                             reinterpret_cast<const void*>(svthip::subpel85_kernel),   reinterpret_cast<const void*>(svthip::subpel_nsq_kernel),
                              reinterpret_cast<const void*>(svthip::bipred_pack_kernel), reinterpret_cast<const void*>(svthip::bipred_nsq_pack_kernel),
                              reinterpret_cast<const void*>(svthip::subpel_planes_kernel), svthip::convolve_compound_kernel_ptr(0),
                              svthip::convolve_compound_kernel_ptr(1),                     svthip::convolve_compound_kernel_ptr(2),
@@ -95,18 +98,74 @@ int32_t scratch_on_stream(svthip_ctx* c, hipStream_t s)
     return SVTHIP_OK;
 }
 
-// Growing a slot frees the old buffer; hipFree synchronises the device first, so work still reading it has finished (growth is rare:
-// the slots only ever grow).
+// Growing a slot is stream-ordered: the old buffer is released with hipFreeAsync behind the last stream that used the context's scratch
+// (every earlier user is ordered before that stream, see scratch_on_stream) and the new one comes from hipMallocAsync on the same
+// stream, so one context's growth never synchronises the device under the other contexts' work (hipFree would: round-2 finding).
+// svthip_reserve pre-sizes the slots so that steady-state calls never get here.
 int32_t ensure_scratch(svthip_ctx* c, int slot, size_t bytes)
 {
     if (c->scratch_bytes[slot] >= bytes) return SVTHIP_OK;
-    if (c->scratch[slot]) HIP_TRY(hipFree(c->scratch[slot]));
+    hipStream_t os = c->scratch_stream ? c->scratch_stream : c->stream;
+    if (c->scratch[slot] && hipFreeAsync(c->scratch[slot], os) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipFree(c->scratch[slot]));
+    }
     c->scratch[slot] = nullptr;
     c->scratch_bytes[slot] = 0;
     size_t want = bytes + bytes / 4 + 4096;
-    if (hipMalloc(&c->scratch[slot], want) != hipSuccess)
-        return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "hipMalloc of %s scratch failed (slot %d)", "device", slot);
+    if (hipMallocAsync(&c->scratch[slot], want, os) != hipSuccess) {
+        (void)hipGetLastError();
+        c->scratch[slot] = nullptr;
+        return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "hipMallocAsync of %s scratch failed (slot %d)", "device", slot);
+    }
     c->scratch_bytes[slot] = want;
+    c->scratch_stream = os;
+    return SVTHIP_OK;
+}
+
+// scratch sizes of the whole-picture ME chain (slot 5: descriptors, per-list arrays, HME state; slot 7: stored predictions)
+size_t me_chain_bytes(size_t n, uint32_t n_pu)
+{
+    const size_t desc_b = sizeof(svthip_fullpel_desc) * n, arr_b = sizeof(uint32_t) * n_pu * n;
+    const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * n) + 15) & ~(size_t)15;
+    return 2 * desc_b + 4 * arr_b + state_b + 64;
+}
+size_t me_pred_bytes(size_t n, uint32_t n_pu) { return 2 * (size_t)(n_pu == 209 ? 14 : 4) * 4096 * n; }
+
+// device pool of the host-pointer picture forms: per picture the padded full plane (stride = width + 136), the 1/4 and the 1/16 plane
+struct HostPoolLayout {
+    uint32_t fs, qs, ss;
+    size_t fb, qb, sb, per;
+};
+HostPoolLayout host_pool_layout(uint32_t w, uint32_t h)
+{
+    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    HostPoolLayout L;
+    L.fs = w + 136; L.qs = (w >> 1) + 64; L.ss = (w >> 2) + 32;
+    L.fb = al((size_t)L.fs * (h + 136)); L.qb = al((size_t)L.qs * ((h >> 1) + 64)); L.sb = al((size_t)L.ss * ((h >> 2) + 32));
+    L.per = L.fb + L.qb + L.sb;
+    return L;
+}
+
+// raster SB origins of a w x h picture in slot 9, rebuilt only when the geometry changes (the upload is from pageable memory, so it is
+// followed by a stream synchronisation; steady-state calls skip both)
+int32_t ensure_sb_table(svthip_ctx* c, uint32_t w, uint32_t h, hipStream_t s)
+{
+    const uint32_t nx = (w + 63) / 64, ny = (h + 63) / 64, n_sb = nx * ny;
+    const bool grew = c->scratch_bytes[9] < sizeof(svthip_sb_origin) * n_sb;
+    int32_t rc;
+    if ((rc = ensure_scratch(c, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
+    if (!grew && c->sb_table_w == w && c->sb_table_h == h) return SVTHIP_OK;
+    svthip_sb_origin* sbs = new (std::nothrow) svthip_sb_origin[n_sb];
+    if (!sbs) return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
+    for (uint32_t y = 0; y < ny; y++)
+        for (uint32_t x = 0; x < nx; x++) sbs[y * nx + x] = svthip_sb_origin{(uint16_t)(x * 64), (uint16_t)(y * 64)};
+    hipError_t e = hipMemcpyAsync(c->scratch[9], sbs, sizeof(svthip_sb_origin) * n_sb, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    delete[] sbs;
+    HIP_TRY(e);
+    c->sb_table_w = w;
+    c->sb_table_h = h;
     return SVTHIP_OK;
 }
 
@@ -185,6 +244,36 @@ int32_t svthip_synchronize(svthip_ctx* ctx)
     return SVTHIP_OK;
 }
 
+int32_t svthip_set_option(svthip_ctx* ctx, int32_t option, int32_t value)
+{
+    if (!ctx) return fail(SVTHIP_ERR_BAD_PARAMETER, "null context%s", "");
+    if (option < 0 || option >= SVTHIP_OPT_COUNT) return fail(SVTHIP_ERR_BAD_PARAMETER, "unknown option%s %d", "", (int)option);
+    ctx->opt[option] = value;
+    return SVTHIP_OK;
+}
+
+int32_t svthip_reserve(svthip_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_pu, uint32_t n_jobs, int32_t host_forms)
+{
+    ENTER(ctx);
+    if ((width & 7) || (height & 7) || !width || !height || width > 16384 || height > 16384)
+        return fail(SVTHIP_ERR_BAD_PARAMETER, "picture dimensions must be non-zero multiples of 8%s (width %d)", "", (int)width);
+    if (n_pu != 85 && n_pu != 209) return fail(SVTHIP_ERR_BAD_PARAMETER, "n_pu must be 85 or 209%s (got %d)", "", (int)n_pu);
+    if (n_jobs == 0) n_jobs = 1;
+    const size_t n_sb = (size_t)((width + 63) / 64) * ((height + 63) / 64), n = n_sb * n_jobs;
+    int32_t rc;
+    if ((rc = ensure_scratch(ctx, 5, me_chain_bytes(n, n_pu)))) return rc;
+    if ((rc = ensure_scratch(ctx, 6, sizeof(uint32_t) * 85 * n))) return rc;
+    if ((rc = ensure_scratch(ctx, 7, me_pred_bytes(n, n_pu)))) return rc;
+    if (host_forms) {
+        const HostPoolLayout L = host_pool_layout(width, height);
+        if ((rc = ensure_scratch(ctx, 8, L.per * 3 + 256))) return rc;
+        if ((rc = ensure_scratch(ctx, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
+        if ((rc = ensure_scratch(ctx, 10, sizeof(svthip_me_cu_result) * n_sb * n_pu))) return rc;
+        if ((rc = ensure_scratch(ctx, 11, sizeof(svthip_me_cu_result_ref) * n_sb * n_pu))) return rc;
+    }
+    return SVTHIP_OK;
+}
+
 int32_t svthip_me_fullpel_search_dev(svthip_ctx* ctx, const uint8_t* d_src_plane, uint32_t src_stride,
                                      const uint8_t* d_ref_plane, uint32_t ref_stride, const svthip_fullpel_desc* d_desc,
                                      uint32_t n_sb, uint32_t max_search_area_width, uint32_t max_search_area_height,
@@ -213,30 +302,14 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
     if ((src_stride & 3u) || (ref_stride & 3u) || (reinterpret_cast<uintptr_t>(d_src_plane) & 3u))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "plane strides and the source plane base must be multiples of 4%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    // default path: the half-pel planes of the whole (bounded) search region interpolated once per (SB, list) in LDS, all PUs in one launch
+    // the half-pel planes of the whole (bounded) search region interpolated once per (SB, list) in LDS, all PUs in one launch; the planes
+    // of the largest legal area (127 x 127) take 152.6 KB, so every legal call fits
     const size_t lds_planes = svthip::subpel_planes_lds_bytes(max_search_area_width, max_search_area_height);
-    if (lds_planes <= 160 * 1024 - 512 && !getenv("SVTHIP_SUBPEL_TILES")) {
-        hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
-                           d_ref_plane, ref_stride, reinterpret_cast<const int32_t*>(d_desc), n_sb, (int)(disable_8x8_refinement != 0), n_pu,
-                           d_best_sad, d_best_mv, d_pred, (int)method);
-        HIP_TRY(hipGetLastError());
-        return SVTHIP_OK;
-    }
-    // per-PU tiles (me_subpel.hip; SVTHIP_SUBPEL_TILES=1, or planes that do not fit): SSD_SEARCH only, the method MotionEstimateLcu uses
-    if (method != SVTHIP_FRACTIONAL_SSD_SEARCH)
-        return fail(SVTHIP_ERR_BAD_PARAMETER, "the SAD search methods are implemented by the plane kernel only%s (method %d)", "", (int)method);
-    const size_t lds = svthip::subpel_lds_bytes(max_search_area_width, max_search_area_height);
-    const size_t lds_nsq = svthip::subpel_nsq_lds_bytes(max_search_area_width, max_search_area_height);
-    if (lds > 160 * 1024 || (n_pu == 209 && lds_nsq > 160 * 1024))
-        return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS window%s", "");
-    hipLaunchKernelGGL(svthip::subpel85_kernel, dim3(n_sb), dim3(256), lds, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                       reinterpret_cast<const int32_t*>(d_desc), (int)disable_8x8_refinement, n_pu, d_best_sad, d_best_mv, d_pred, n_pu == 209 ? 14 : 4);
+    if (lds_planes > 160 * 1024 - 512) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS planes%s", "");
+    hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
+                       d_ref_plane, ref_stride, reinterpret_cast<const int32_t*>(d_desc), n_sb, (int)(disable_8x8_refinement != 0), n_pu,
+                       d_best_sad, d_best_mv, d_pred, (int)method);
     HIP_TRY(hipGetLastError());
-    if (n_pu == 209) {
-        hipLaunchKernelGGL(svthip::subpel_nsq_kernel, dim3(n_sb), dim3(320), lds_nsq, s, d_src_plane, src_stride, d_ref_plane, ref_stride,
-                           reinterpret_cast<const int32_t*>(d_desc), d_best_sad, d_best_mv, d_pred);
-        HIP_TRY(hipGetLastError());
-    }
     return SVTHIP_OK;
 }
 
@@ -538,9 +611,8 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
     const size_t n = (size_t)n_jobs * n_sb;
     // scratch: slot 5 holds  desc[2][n] | sad[2][n][n_pu] | mv[2][n][n_pu] | hme_state[n][25]
     const size_t desc_b = sizeof(svthip_fullpel_desc) * n, arr_b = sizeof(uint32_t) * n_pu * n;
-    const size_t state_b = ((sizeof(int16_t) * SVTHIP_HME_STATE_INT16 * n) + 15) & ~(size_t)15;
     int32_t rc;
-    if ((rc = ensure_scratch(ctx, 5, 2 * desc_b + 4 * arr_b + state_b + 64))) return rc;
+    if ((rc = ensure_scratch(ctx, 5, me_chain_bytes(n, n_pu)))) return rc;
     uint8_t* base = static_cast<uint8_t*>(ctx->scratch[5]);
     svthip_fullpel_desc* desc[2] = {reinterpret_cast<svthip_fullpel_desc*>(base), reinterpret_cast<svthip_fullpel_desc*>(base + desc_b)};
     uint32_t* sad[2] = {reinterpret_cast<uint32_t*>(base + 2 * desc_b), reinterpret_cast<uint32_t*>(base + 2 * desc_b + arr_b)};
@@ -560,7 +632,7 @@ static int32_t motion_estimate_batch_common(svthip_ctx* ctx, const uint8_t* d_po
     const size_t pred_b = (size_t)(n_pu == 209 ? 14 : 4) * 4096 * n;
     uint8_t* pred[2] = {nullptr, nullptr};
     if (n_lists == 2 && use_subpel_flag) {
-        if ((rc = ensure_scratch(ctx, 7, 2 * pred_b))) return rc;
+        if ((rc = ensure_scratch(ctx, 7, me_pred_bytes(n, n_pu)))) return rc;
         pred[0] = static_cast<uint8_t*>(ctx->scratch[7]);
         pred[1] = pred[0] + pred_b;
     }
@@ -650,16 +722,24 @@ int32_t svthip_me_fullpel_search(svthip_ctx* ctx, const uint8_t* src_plane, size
     if ((rc = ensure_scratch(ctx, 3, sizeof(uint32_t) * 85 * n_sb))) return rc;
     if ((rc = ensure_scratch(ctx, 4, sizeof(uint32_t) * 85 * n_sb))) return rc;
     hipStream_t s = ctx->stream;
-    HIP_TRY(hipMemcpyAsync(ctx->scratch[0], src_plane, src_plane_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->scratch[1], ref_plane, ref_plane_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ctx->scratch[2], desc, sizeof(svthip_fullpel_desc) * n_sb, hipMemcpyHostToDevice, s));
-    rc = launch_fullpel(ctx, (const uint8_t*)ctx->scratch[0], src_stride, (const uint8_t*)ctx->scratch[1], ref_stride,
-                        (const svthip_fullpel_desc*)ctx->scratch[2], n_sb, max_sw, max_sh, (uint32_t*)ctx->scratch[3],
-                        (uint32_t*)ctx->scratch[4], s);
+    if ((rc = scratch_on_stream(ctx, s))) return rc;
+    // copies from / to the caller's buffers are in flight inside `queued`: every exit synchronises the stream first
+    auto queued = [&]() -> int32_t {
+        HIP_TRY(hipMemcpyAsync(ctx->scratch[0], src_plane, src_plane_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ctx->scratch[1], ref_plane, ref_plane_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ctx->scratch[2], desc, sizeof(svthip_fullpel_desc) * n_sb, hipMemcpyHostToDevice, s));
+        int32_t r = launch_fullpel(ctx, (const uint8_t*)ctx->scratch[0], src_stride, (const uint8_t*)ctx->scratch[1], ref_stride,
+                                   (const svthip_fullpel_desc*)ctx->scratch[2], n_sb, max_sw, max_sh, (uint32_t*)ctx->scratch[3],
+                                   (uint32_t*)ctx->scratch[4], s);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(best_sad, ctx->scratch[3], sizeof(uint32_t) * 85 * n_sb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(best_mv, ctx->scratch[4], sizeof(uint32_t) * 85 * n_sb, hipMemcpyDeviceToHost, s));
+        return SVTHIP_OK;
+    };
+    rc = queued();
+    const hipError_t sync_e = hipStreamSynchronize(s);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(best_sad, ctx->scratch[3], sizeof(uint32_t) * 85 * n_sb, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(best_mv, ctx->scratch[4], sizeof(uint32_t) * 85 * n_sb, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(sync_e);
     return SVTHIP_OK;
 }
 
@@ -725,7 +805,7 @@ int32_t svthip_sad_loop_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, uint32_
     if (n_blocks == 0) return SVTHIP_OK;
     if (!d_src || !d_ref || !d_desc || !d_best_sad || !d_best_xy) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if ((width == 4 || width == 8 || width == 16 || width == 32 || width == 64) && !getenv("SVTHIP_SADLOOP_GENERIC")) {
+    if ((width == 4 || width == 8 || width == 16 || width == 32 || width == 64) && !ctx->opt[SVTHIP_OPT_SADLOOP_GENERIC]) {
         // packed-SAD kernel (eight positions per lane); falls through to the generic one when its slightly wider window rows do not fit
         const size_t qs = svthip::sad_loop_qsad_slice_bytes((int)width, (int)height, (int)search_area_width, (int)search_area_height,
                                                             (int)(ref_stride / ref_stride_raw));
@@ -754,7 +834,7 @@ int32_t svthip_av1_convolve_sr_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, 
     if (!d_src || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (reinterpret_cast<uintptr_t>(d_desc) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !getenv("SVTHIP_CONVOLVE_VALU")) {
+    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !ctx->opt[SVTHIP_OPT_CONVOLVE_VALU]) {
         // sides that are multiples of 32: both passes as exact i8 matrix products on the matrix cores (ip_convolve_mfma.hip)
         HIP_TRY(svthip::launch_av1_convolve_sr_mfma(d_src, src_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width, (int)height, s));
         return SVTHIP_OK;
@@ -786,7 +866,7 @@ int32_t svthip_av1_convolve_compound_batch_dev(svthip_ctx* ctx, const uint8_t* d
     if (!d_src0 || !d_src1 || !d_dst || !d_desc) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     if (reinterpret_cast<uintptr_t>(d_desc) & 15u) return fail(SVTHIP_ERR_BAD_PARAMETER, "descriptor array must be 16-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !getenv("SVTHIP_CONVOLVE_VALU")) {
+    if (svthip::convolve_mfma_size_valid((int)width, (int)height) && !ctx->opt[SVTHIP_OPT_CONVOLVE_VALU]) {
         HIP_TRY(svthip::launch_av1_convolve_compound_mfma(d_src0, src0_stride, d_src1, src1_stride, d_dst, dst_stride, d_desc, n_blocks, (int)width,
                                                           (int)height, s));
         return SVTHIP_OK;
@@ -864,53 +944,58 @@ int32_t svthip_motion_estimate_picture(svthip_ctx* ctx, const svthip_host_pictur
             hp[i]->stride_y < w + 136u)
             return fail(SVTHIP_ERR_BAD_PARAMETER, "picture %s%d: needs a luma plane of the same size with origin (68,68) and stride >= width + 136", "", i);
     }
-    // device pool: per picture the padded full plane (stride = width + 136), the 1/4 and the 1/16 plane
-    const uint32_t fs = w + 136, qs = (w >> 1) + 64, ss = (w >> 2) + 32;
-    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t fb = al((size_t)fs * (h + 136)), qb = al((size_t)qs * ((h >> 1) + 64)), sb_ = al((size_t)ss * ((h >> 2) + 32));
-    const size_t per = fb + qb + sb_;
-    const uint32_t nx = (w + 63) / 64, ny = (h + 63) / 64, n_sb = nx * ny;
+    const uint32_t n_sb = ((w + 63) / 64) * ((h + 63) / 64);
+    for (uint32_t i = 0; i < n_sb; i++)  // every caller row is checked BEFORE any work is queued: no transfer ever outlives a failed call
+        if (!me_results[i]) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results[%s%d] is null", "", (int)i);
+    const HostPoolLayout L = host_pool_layout(w, h);
     int32_t rc;
-    if ((rc = ensure_scratch(ctx, 8, per * n_pic + 256))) return rc;
-    if ((rc = ensure_scratch(ctx, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
+    if ((rc = ensure_scratch(ctx, 8, L.per * n_pic + 256))) return rc;
     if ((rc = ensure_scratch(ctx, 10, sizeof(svthip_me_cu_result) * (size_t)n_sb * n_pu))) return rc;
     if ((rc = ensure_scratch(ctx, 11, sizeof(svthip_me_cu_result_ref) * (size_t)n_sb * n_pu))) return rc;
     hipStream_t s = ctx->stream;
     if ((rc = scratch_on_stream(ctx, s))) return rc;
-    uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
-    svthip_pa_picture pd[3];
-    for (int i = 0; i < n_pic; i++) {
-        pd[i].full_offset = (int64_t)(per * i);
-        pd[i].quarter_offset = (int64_t)(per * i + fb);
-        pd[i].sixteenth_offset = (int64_t)(per * i + fb + qb);
-        pd[i].full_stride = fs; pd[i].quarter_stride = qs; pd[i].sixteenth_stride = ss;
-        pd[i].width = (uint16_t)w; pd[i].height = (uint16_t)h;
-        // the picture rows only (borders and decimated planes are derived on the device, bit-identically to Picture Analysis)
-        HIP_TRY(hipMemcpy2DAsync(pool + per * i + (size_t)68 * fs + 68, fs, hp[i]->buffer_y + (size_t)68 * hp[i]->stride_y + 68, hp[i]->stride_y,
-                                 w, h, hipMemcpyHostToDevice, s));
-    }
-    svthip_sb_origin* sbs = new (std::nothrow) svthip_sb_origin[n_sb];
-    if (!sbs) return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
-    for (uint32_t y = 0; y < ny; y++)
-        for (uint32_t x = 0; x < nx; x++) sbs[y * nx + x] = svthip_sb_origin{(uint16_t)(x * 64), (uint16_t)(y * 64)};
-    hipError_t e = hipMemcpyAsync(ctx->scratch[9], sbs, sizeof(svthip_sb_origin) * n_sb, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);  // sbs is pageable: the copy has left it before it is freed
-    delete[] sbs;
-    HIP_TRY(e);
-    if ((rc = svthip_pa_derive_planes_dev(ctx, pool, pd, (uint32_t)n_pic, params->enable_hme_level1_flag, params->enable_hme_level0_flag, s))) return rc;
-    svthip_me_cu_result* d_res = static_cast<svthip_me_cu_result*>(ctx->scratch[10]);
-    rc = n_pu == 209 ? svthip_motion_estimate209_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode,
-                                                           static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb, d_res, nullptr, nullptr, s)
-                     : svthip_motion_estimate_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode,
-                                                        static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb, d_res, nullptr, nullptr, s);
+    if ((rc = ensure_sb_table(ctx, w, h, s))) return rc;
+    // from here on copies from / to the caller's buffers are in flight: every exit synchronises the stream first
+    auto queued = [&]() -> int32_t {
+        uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
+        svthip_pa_picture pd[3];
+        for (int i = 0; i < n_pic; i++) {
+            pd[i].full_offset = (int64_t)(L.per * i);
+            pd[i].quarter_offset = (int64_t)(L.per * i + L.fb);
+            pd[i].sixteenth_offset = (int64_t)(L.per * i + L.fb + L.qb);
+            pd[i].full_stride = L.fs; pd[i].quarter_stride = L.qs; pd[i].sixteenth_stride = L.ss;
+            pd[i].width = (uint16_t)w; pd[i].height = (uint16_t)h;
+            // the picture rows only (borders and decimated planes are derived on the device, bit-identically to Picture Analysis)
+            HIP_TRY(hipMemcpy2DAsync(pool + L.per * i + (size_t)68 * L.fs + 68, L.fs, hp[i]->buffer_y + (size_t)68 * hp[i]->stride_y + 68,
+                                     hp[i]->stride_y, w, h, hipMemcpyHostToDevice, s));
+        }
+        int32_t r;
+        if ((r = svthip_pa_derive_planes_dev(ctx, pool, pd, (uint32_t)n_pic, params->enable_hme_level1_flag, params->enable_hme_level0_flag, s))) return r;
+        svthip_me_cu_result* d_res = static_cast<svthip_me_cu_result*>(ctx->scratch[10]);
+        const svthip_sb_origin* d_sb = static_cast<const svthip_sb_origin*>(ctx->scratch[9]);
+        r = n_pu == 209 ? svthip_motion_estimate209_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode,
+                                                              d_sb, n_sb, d_res, nullptr, nullptr, s)
+                        : svthip_motion_estimate_batch_dev(ctx, pool, &pd[0], &pd[1], ref1 ? &pd[2] : nullptr, 1, params, use_subpel_flag, cu8x8_mode, d_sb,
+                                                           n_sb, d_res, nullptr, nullptr, s);
+        if (r) return r;
+        svthip_me_cu_result_ref* d_ref = static_cast<svthip_me_cu_result_ref*>(ctx->scratch[11]);
+        if ((r = svthip_me_results_to_ref_layout_dev(ctx, d_res, n_sb * n_pu, d_ref, s))) return r;
+        // rows of one allocation (the reference's EB_MALLOC'd me_results rows usually are not) leave in one copy
+        bool contiguous = true;
+        for (uint32_t i = 1; i < n_sb && contiguous; i++)
+            contiguous = static_cast<uint8_t*>(me_results[i]) == static_cast<uint8_t*>(me_results[0]) + sizeof(svthip_me_cu_result_ref) * (size_t)n_pu * i;
+        if (contiguous) {
+            HIP_TRY(hipMemcpyAsync(me_results[0], d_ref, sizeof(svthip_me_cu_result_ref) * (size_t)n_pu * n_sb, hipMemcpyDeviceToHost, s));
+        } else {
+            for (uint32_t i = 0; i < n_sb; i++)
+                HIP_TRY(hipMemcpyAsync(me_results[i], d_ref + (size_t)i * n_pu, sizeof(svthip_me_cu_result_ref) * n_pu, hipMemcpyDeviceToHost, s));
+        }
+        return SVTHIP_OK;
+    };
+    rc = queued();
+    const hipError_t sync_e = hipStreamSynchronize(s);
     if (rc) return rc;
-    svthip_me_cu_result_ref* d_ref = static_cast<svthip_me_cu_result_ref*>(ctx->scratch[11]);
-    if ((rc = svthip_me_results_to_ref_layout_dev(ctx, d_res, n_sb * n_pu, d_ref, s))) return rc;
-    for (uint32_t i = 0; i < n_sb; i++) {
-        if (!me_results[i]) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results[%s%d] is null", "", (int)i);
-        HIP_TRY(hipMemcpyAsync(me_results[i], d_ref + (size_t)i * n_pu, sizeof(svthip_me_cu_result_ref) * n_pu, hipMemcpyDeviceToHost, s));
-    }
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(sync_e);
     return SVTHIP_OK;
 }
 
@@ -926,57 +1011,56 @@ int32_t svthip_open_loop_intra_search_picture(svthip_ctx* ctx, const svthip_host
                          !params->limit_ois_to_dc_mode_flag;
     if (general && (!me_results || (n_pu != 85 && n_pu != 209)))
         return fail(SVTHIP_ERR_BAD_PARAMETER, "this picture's branch reads me_results (n_pu 85 or 209)%s (n_pu %d)", "", (int)n_pu);
-    const uint32_t fs = w + 136, nx = (w + 63) / 64, ny = (h + 63) / 64, n_sb = nx * ny;
+    const uint32_t fs = w + 136, n_sb = ((w + 63) / 64) * ((h + 63) / 64);
     const size_t cand_bytes = (size_t)n_sb * 85 * 18 * 4, total_bytes = (size_t)n_sb * 85;
+    if (general)
+        for (uint32_t i = 0; i < n_sb; i++)  // checked before any work is queued
+            if (!me_results[i]) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results[%s%d] is null", "", (int)i);
     int32_t rc;
     if ((rc = ensure_scratch(ctx, 8, (size_t)fs * (h + 136) + 256))) return rc;
-    if ((rc = ensure_scratch(ctx, 9, sizeof(svthip_sb_origin) * n_sb))) return rc;
     if ((rc = ensure_scratch(ctx, 10, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85))) return rc;
     if ((rc = ensure_scratch(ctx, 11, cand_bytes + total_bytes))) return rc;
     hipStream_t s = ctx->stream;
     if ((rc = scratch_on_stream(ctx, s))) return rc;
-    uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
-    // only the picture interior is ever read by the search (samples outside the picture count as 128): any origin is accepted
-    HIP_TRY(hipMemcpy2DAsync(pool + (size_t)68 * fs + 68, fs, cur->buffer_y + (size_t)cur->origin_y * cur->stride_y + cur->origin_x, cur->stride_y, w, h,
-                             hipMemcpyHostToDevice, s));
-    svthip_sb_origin* sbs = new (std::nothrow) svthip_sb_origin[n_sb];
-    svthip_me_cu_result* rows = general ? new (std::nothrow) svthip_me_cu_result[(size_t)n_sb * 85] : nullptr;
-    if (!sbs || (general && !rows)) {
-        delete[] sbs;
-        delete[] rows;
-        return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of host memory%s", "");
-    }
-    for (uint32_t y = 0; y < ny; y++)
-        for (uint32_t x = 0; x < nx; x++) sbs[y * nx + x] = svthip_sb_origin{(uint16_t)(x * 64), (uint16_t)(y * 64)};
-    hipError_t e = hipSuccess;
+    if ((rc = ensure_sb_table(ctx, w, h, s))) return rc;
+    svthip_me_cu_result* rows = nullptr;
     if (general) {
+        // pinned staging for the ME distortions: the copy may still be reading it when this function queues the kernel
+        if (hipHostMalloc(reinterpret_cast<void**>(&rows), sizeof(svthip_me_cu_result) * (size_t)n_sb * 85, hipHostMallocDefault) != hipSuccess)
+            return fail(SVTHIP_ERR_INSUFFICIENT_RESOURCES, "out of pinned host memory%s", "");
         memset(rows, 0, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85);
-        for (uint32_t i = 0; i < n_sb && e == hipSuccess; i++) {
-            if (!me_results[i]) { e = hipErrorInvalidValue; break; }
+        for (uint32_t i = 0; i < n_sb; i++) {
             const svthip_me_cu_result_ref* r = static_cast<const svthip_me_cu_result_ref*>(me_results[i]);
             for (uint32_t cu = 0; cu < 85; cu++) rows[(size_t)i * 85 + cu].distortion[0] = r[cu].distortionDirection[0].distortion;
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->scratch[10], rows, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85, hipMemcpyHostToDevice, s);
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->scratch[9], sbs, sizeof(svthip_sb_origin) * n_sb, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);  // the staging arrays are pageable: the copies have left them before they are freed
-    delete[] sbs;
-    delete[] rows;
-    if (e == hipErrorInvalidValue) return fail(SVTHIP_ERR_BAD_PARAMETER, "me_results row pointer is null%s", "");
-    HIP_TRY(e);
-    svthip_pa_picture pd;
-    memset(&pd, 0, sizeof(pd));
-    pd.full_stride = fs;
-    pd.width = (uint16_t)w;
-    pd.height = (uint16_t)h;
-    uint32_t* d_cand = static_cast<uint32_t*>(ctx->scratch[11]);
-    uint8_t* d_total = static_cast<uint8_t*>(ctx->scratch[11]) + cand_bytes;
-    if ((rc = svthip_open_loop_intra_search_batch_dev(ctx, pool, &pd, 1, params, static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb,
-                                                      general ? static_cast<const svthip_me_cu_result*>(ctx->scratch[10]) : nullptr, 85, d_cand, d_total, s)))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(cand, d_cand, cand_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(total, d_total, total_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // from here on copies from / to the caller's buffers are in flight: every exit synchronises the stream first
+    auto queued = [&]() -> int32_t {
+        uint8_t* pool = static_cast<uint8_t*>(ctx->scratch[8]);
+        // only the picture interior is ever read by the search (samples outside the picture count as 128): any origin is accepted
+        HIP_TRY(hipMemcpy2DAsync(pool + (size_t)68 * fs + 68, fs, cur->buffer_y + (size_t)cur->origin_y * cur->stride_y + cur->origin_x, cur->stride_y, w,
+                                 h, hipMemcpyHostToDevice, s));
+        if (general) HIP_TRY(hipMemcpyAsync(ctx->scratch[10], rows, sizeof(svthip_me_cu_result) * (size_t)n_sb * 85, hipMemcpyHostToDevice, s));
+        svthip_pa_picture pd;
+        memset(&pd, 0, sizeof(pd));
+        pd.full_stride = fs;
+        pd.width = (uint16_t)w;
+        pd.height = (uint16_t)h;
+        uint32_t* d_cand = static_cast<uint32_t*>(ctx->scratch[11]);
+        uint8_t* d_total = static_cast<uint8_t*>(ctx->scratch[11]) + cand_bytes;
+        int32_t r;
+        if ((r = svthip_open_loop_intra_search_batch_dev(ctx, pool, &pd, 1, params, static_cast<const svthip_sb_origin*>(ctx->scratch[9]), n_sb,
+                                                         general ? static_cast<const svthip_me_cu_result*>(ctx->scratch[10]) : nullptr, 85, d_cand, d_total, s)))
+            return r;
+        HIP_TRY(hipMemcpyAsync(cand, d_cand, cand_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(total, d_total, total_bytes, hipMemcpyDeviceToHost, s));
+        return SVTHIP_OK;
+    };
+    rc = queued();
+    const hipError_t sync_e = hipStreamSynchronize(s);
+    if (rows) (void)hipHostFree(rows);
+    if (rc) return rc;
+    HIP_TRY(sync_e);
     return SVTHIP_OK;
 }
 
@@ -1028,26 +1112,33 @@ int32_t svthip_encode_tu_batch(svthip_ctx* ctx, const void* src, const void* pre
     uint16_t* d_eob = reinterpret_cast<uint16_t*>(p15);
     uint64_t* d_en = three_quad_energy ? reinterpret_cast<uint64_t*>(p15 + al(2 * (size_t)n_tu)) : nullptr;
     uint64_t* d_dist = distortion ? reinterpret_cast<uint64_t*>(p15 + al(2 * (size_t)n_tu) + al(8 * (size_t)n_tu)) : nullptr;
-    HIP_TRY(hipMemcpyAsync(d_src, src, pb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_pred, pred, pb, hipMemcpyHostToDevice, s));
-    if (!in_place) HIP_TRY(hipMemcpyAsync(d_recon, recon, pb, hipMemcpyHostToDevice, s));  // samples outside the TUs keep the caller's values
-    HIP_TRY(hipMemcpyAsync(d_desc, desc, sizeof(svthip_tu_desc) * n_tu, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_qp, qparams, 20 * (size_t)n_qparam_rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_iscan, iscan, 2 * (size_t)n_iscan, hipMemcpyHostToDevice, s));
-    // pool words no TU covers come back as the caller left them
-    if (coeff) HIP_TRY(hipMemcpyAsync(d_coeff, coeff, cb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_q, qcoeff, cb, hipMemcpyHostToDevice, s));
-    if (dqcoeff) HIP_TRY(hipMemcpyAsync(d_dq, dqcoeff, cb, hipMemcpyHostToDevice, s));
-    HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit ? 1 : 0, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qp, d_iscan, d_coeff,
-                                     d_q, d_dq, d_eob, d_en, d_dist, s));
-    HIP_TRY(hipMemcpyAsync(recon, d_recon, pb, hipMemcpyDeviceToHost, s));
-    if (coeff) HIP_TRY(hipMemcpyAsync(coeff, d_coeff, cb, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(qcoeff, d_q, cb, hipMemcpyDeviceToHost, s));
-    if (dqcoeff) HIP_TRY(hipMemcpyAsync(dqcoeff, d_dq, cb, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(eob, d_eob, 2 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
-    if (three_quad_energy) HIP_TRY(hipMemcpyAsync(three_quad_energy, d_en, 8 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
-    if (distortion) HIP_TRY(hipMemcpyAsync(distortion, d_dist, 16 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // copies from / to the caller's buffers are in flight inside `queued`: every exit synchronises the stream first
+    auto queued = [&]() -> int32_t {
+        HIP_TRY(hipMemcpyAsync(d_src, src, pb, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_pred, pred, pb, hipMemcpyHostToDevice, s));
+        if (!in_place) HIP_TRY(hipMemcpyAsync(d_recon, recon, pb, hipMemcpyHostToDevice, s));  // samples outside the TUs keep the caller's values
+        HIP_TRY(hipMemcpyAsync(d_desc, desc, sizeof(svthip_tu_desc) * n_tu, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_qp, qparams, 20 * (size_t)n_qparam_rows, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_iscan, iscan, 2 * (size_t)n_iscan, hipMemcpyHostToDevice, s));
+        // pool words no TU covers come back as the caller left them
+        if (coeff) HIP_TRY(hipMemcpyAsync(d_coeff, coeff, cb, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_q, qcoeff, cb, hipMemcpyHostToDevice, s));
+        if (dqcoeff) HIP_TRY(hipMemcpyAsync(d_dq, dqcoeff, cb, hipMemcpyHostToDevice, s));
+        HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit ? 1 : 0, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qp, d_iscan, d_coeff,
+                                         d_q, d_dq, d_eob, d_en, d_dist, s));
+        HIP_TRY(hipMemcpyAsync(recon, d_recon, pb, hipMemcpyDeviceToHost, s));
+        if (coeff) HIP_TRY(hipMemcpyAsync(coeff, d_coeff, cb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(qcoeff, d_q, cb, hipMemcpyDeviceToHost, s));
+        if (dqcoeff) HIP_TRY(hipMemcpyAsync(dqcoeff, d_dq, cb, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(eob, d_eob, 2 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+        if (three_quad_energy) HIP_TRY(hipMemcpyAsync(three_quad_energy, d_en, 8 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+        if (distortion) HIP_TRY(hipMemcpyAsync(distortion, d_dist, 16 * (size_t)n_tu, hipMemcpyDeviceToHost, s));
+        return SVTHIP_OK;
+    };
+    rc = queued();
+    const hipError_t sync_e = hipStreamSynchronize(s);
+    if (rc) return rc;
+    HIP_TRY(sync_e);
     return SVTHIP_OK;
 }
 
@@ -1057,24 +1148,27 @@ int32_t svthip_me_fullpel_search_time_dev(svthip_ctx* ctx, const uint8_t* d_src_
                                           uint32_t max_search_area_height, uint32_t* d_best_sad, uint32_t* d_best_mv,
                                           uint32_t iters, float* avg_ms)
 {
-    if (!ctx || !avg_ms || iters == 0) return fail(SVTHIP_ERR_BAD_PARAMETER, "bad timing arguments%s", "");
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    ENTER(ctx);
+    if (!avg_ms || iters == 0) return fail(SVTHIP_ERR_BAD_PARAMETER, "bad timing arguments%s", "");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t s = ctx->stream;
     int32_t rc = SVTHIP_OK;
-    HIP_TRY(hipEventRecord(e0, s));
-    for (uint32_t i = 0; i < iters && rc == SVTHIP_OK; i++)
+    float ms = 0.f;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    for (uint32_t i = 0; e == hipSuccess && i < iters && rc == SVTHIP_OK; i++)
         rc = launch_fullpel(ctx, d_src_plane, src_stride, d_ref_plane, ref_stride, d_desc, n_sb, max_search_area_width,
                             max_search_area_height, d_best_sad, d_best_mv, s);
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    HIP_TRY(e);
     *avg_ms = ms / (float)iters;
-    return rc;
+    return SVTHIP_OK;
 }
 
 }  // extern "C"

@@ -44,11 +44,13 @@ struct svthip_tu_batcher {
     int32_t *d_q, *d_dq;
     uint8_t* d_recon_scratch;
     svthip_tu_desc* d_desc;
-    uint16_t* d_eob;
-    uint64_t *d_energy, *d_dist;
-    // host mirrors of the per-candidate outputs (pinned)
-    uint16_t* h_eob;
-    uint64_t *h_energy, *h_dist;
+    // per-candidate outputs, ONE device block and ONE pinned mirror so that a flush is one upload, the launches, one download:
+    // [dist 16 B x max_cand][energy 8 B x max_cand][eob 2 B x max_cand]
+    uint8_t *d_out, *h_out;
+    uint64_t *d_dist, *d_energy, *h_dist, *h_energy;
+    uint16_t *d_eob, *h_eob;
+    svthip_tu_desc* h_desc;  // pinned: descriptors in launch order
+    std::vector<uint32_t> launch_handle;
     std::vector<svthip_tu_result> results;
 };
 
@@ -68,26 +70,28 @@ int32_t svthip_tu_batcher_create(svthip_ctx* ctx, uint32_t max_candidates, uint3
     b->coeff_used = b->recon_used = b->flushed = 0;
     b->d_q = b->d_dq = nullptr;
     b->d_recon_scratch = nullptr;
-    b->d_desc = nullptr;
-    b->d_eob = nullptr;
-    b->d_energy = b->d_dist = nullptr;
-    b->h_eob = nullptr;
-    b->h_energy = b->h_dist = nullptr;
+    b->d_desc = b->h_desc = nullptr;
+    b->d_out = b->h_out = nullptr;
     if (svthip_synchronize(ctx) != SVTHIP_OK) { delete b; return SVTHIP_ERR_DEVICE; }  // makes the context's device current
+    const size_t nc = max_candidates, out_bytes = 26 * nc + 64;
     bool ok = hipMalloc(reinterpret_cast<void**>(&b->d_q), sizeof(int32_t) * b->max_coeff) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&b->d_dq), sizeof(int32_t) * b->max_coeff) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&b->d_recon_scratch), 2 * b->max_recon + 64) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&b->d_desc), sizeof(svthip_tu_desc) * max_candidates) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&b->d_eob), 2 * (size_t)max_candidates) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&b->d_energy), 8 * (size_t)max_candidates) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void**>(&b->d_dist), 16 * (size_t)max_candidates) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&b->h_eob), 2 * (size_t)max_candidates) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&b->h_energy), 8 * (size_t)max_candidates) == hipSuccess &&
-              hipHostMalloc(reinterpret_cast<void**>(&b->h_dist), 16 * (size_t)max_candidates) == hipSuccess;
+              hipMalloc(reinterpret_cast<void**>(&b->d_desc), sizeof(svthip_tu_desc) * nc) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&b->d_out), out_bytes) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&b->h_out), out_bytes) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&b->h_desc), sizeof(svthip_tu_desc) * nc) == hipSuccess;
     if (!ok) {
         svthip_tu_batcher_destroy(b);
         return SVTHIP_ERR_INSUFFICIENT_RESOURCES;
     }
+    b->d_dist = reinterpret_cast<uint64_t*>(b->d_out);
+    b->d_energy = reinterpret_cast<uint64_t*>(b->d_out + 16 * nc);
+    b->d_eob = reinterpret_cast<uint16_t*>(b->d_out + 24 * nc);
+    b->h_dist = reinterpret_cast<uint64_t*>(b->h_out);
+    b->h_energy = reinterpret_cast<uint64_t*>(b->h_out + 16 * nc);
+    b->h_eob = reinterpret_cast<uint16_t*>(b->h_out + 24 * nc);
+    b->launch_handle.reserve(max_candidates);
     b->cands.reserve(max_candidates);
     b->results.reserve(max_candidates);
     *out = b;
@@ -102,12 +106,9 @@ void svthip_tu_batcher_destroy(svthip_tu_batcher* b)
     (void)hipFree(b->d_dq);
     (void)hipFree(b->d_recon_scratch);
     (void)hipFree(b->d_desc);
-    (void)hipFree(b->d_eob);
-    (void)hipFree(b->d_energy);
-    (void)hipFree(b->d_dist);
-    if (b->h_eob) (void)hipHostFree(b->h_eob);
-    if (b->h_energy) (void)hipHostFree(b->h_energy);
-    if (b->h_dist) (void)hipHostFree(b->h_dist);
+    (void)hipFree(b->d_out);
+    if (b->h_out) (void)hipHostFree(b->h_out);
+    if (b->h_desc) (void)hipHostFree(b->h_desc);
     delete b;
 }
 
@@ -181,45 +182,46 @@ int32_t svthip_tu_batcher_flush(svthip_tu_batcher* b)
     hipStream_t s = static_cast<hipStream_t>(svthip_stream(b->ctx));
     b->results.resize(b->cands.size());
     // Two launches per size at most: candidates reconstructing into the caller's plane and candidates reconstructing into scratch
-    // (a launch has ONE reconstruction plane).  Groups are uploaded back to back; `base` = first candidate of the launch.
-    size_t base = 0;
-    std::vector<svthip_tu_desc> part;
-    std::vector<uint32_t> part_handle;
-    for (int ts = 0; ts < 19; ts++) {
+    // (a launch has ONE reconstruction plane).  All descriptors go to the pinned array in launch order and up in ONE copy; the launches
+    // follow on the same stream with no host synchronisation in between; the three output arrays come back in ONE copy.
+    struct Launch { int ts, scratch; uint32_t base, n; };
+    Launch launches[38];
+    int n_launch = 0;
+    uint32_t base = 0;
+    b->launch_handle.clear();
+    for (int ts = 0; ts < 19; ts++)
         for (int scratch = 0; scratch < 2; scratch++) {
-            part.clear();
-            part_handle.clear();
+            const uint32_t first = base;
             for (size_t i = 0; i < b->group[ts].size(); i++)
                 if ((int)b->group[ts][i].reserved[0] == scratch) {
                     svthip_tu_desc d = b->group[ts][i];
-                    d.reserved[0] = 0;
-                    part.push_back(d);
-                    part_handle.push_back(b->group_handle[ts][i]);
+                    d.reserved[0] = 0;  // host-side tag
+                    b->h_desc[base++] = d;
+                    b->launch_handle.push_back(b->group_handle[ts][i]);
                 }
-            if (part.empty()) continue;
-            const uint32_t n = (uint32_t)part.size();
-            if (hipMemcpyAsync(b->d_desc + base, part.data(), sizeof(svthip_tu_desc) * n, hipMemcpyHostToDevice, s) != hipSuccess) return SVTHIP_ERR_DEVICE;
-            if (hipStreamSynchronize(s) != hipSuccess) return SVTHIP_ERR_DEVICE;  // `part` is reused by the next group
-            void* recon = scratch ? static_cast<void*>(b->d_recon_scratch) : b->d_recon;
-            int32_t rc = b->planes_16bit
-                             ? svthip_encode_tu16_batch_dev(b->ctx, static_cast<const uint16_t*>(b->d_src), static_cast<const uint16_t*>(b->d_pred),
-                                                            static_cast<uint16_t*>(recon), b->d_desc + base, n, kTxW[ts], kTxH[ts], b->d_qparams, b->d_iscan,
-                                                            nullptr, b->d_q, b->d_dq, b->d_eob + base, b->d_energy + base, b->d_dist + 2 * base, s)
-                             : svthip_encode_tu_batch_dev(b->ctx, static_cast<const uint8_t*>(b->d_src), static_cast<const uint8_t*>(b->d_pred),
-                                                          static_cast<uint8_t*>(recon), b->d_desc + base, n, kTxW[ts], kTxH[ts], b->d_qparams, b->d_iscan,
-                                                          nullptr, b->d_q, b->d_dq, b->d_eob + base, b->d_energy + base, b->d_dist + 2 * base, s);
-            if (rc) return rc;
-            for (uint32_t i = 0; i < n; i++) {
-                svthip_tu_result& r = b->results[part_handle[i]];
-                r.coeff_offset = (uint32_t)(base + i);  // position in the output arrays until the copy below lands
-            }
-            base += n;
+            if (base != first) launches[n_launch++] = Launch{ts, scratch, first, base - first};
+        }
+    const size_t total = base;
+    if (hipMemcpyAsync(b->d_desc, b->h_desc, sizeof(svthip_tu_desc) * total, hipMemcpyHostToDevice, s) != hipSuccess) return SVTHIP_ERR_DEVICE;
+    for (int k = 0; k < n_launch; k++) {
+        const Launch& L = launches[k];
+        void* recon = L.scratch ? static_cast<void*>(b->d_recon_scratch) : b->d_recon;
+        int32_t rc = b->planes_16bit
+                         ? svthip_encode_tu16_batch_dev(b->ctx, static_cast<const uint16_t*>(b->d_src), static_cast<const uint16_t*>(b->d_pred),
+                                                        static_cast<uint16_t*>(recon), b->d_desc + L.base, L.n, kTxW[L.ts], kTxH[L.ts], b->d_qparams,
+                                                        b->d_iscan, nullptr, b->d_q, b->d_dq, b->d_eob + L.base, b->d_energy + L.base,
+                                                        b->d_dist + 2 * (size_t)L.base, s)
+                         : svthip_encode_tu_batch_dev(b->ctx, static_cast<const uint8_t*>(b->d_src), static_cast<const uint8_t*>(b->d_pred),
+                                                      static_cast<uint8_t*>(recon), b->d_desc + L.base, L.n, kTxW[L.ts], kTxH[L.ts], b->d_qparams,
+                                                      b->d_iscan, nullptr, b->d_q, b->d_dq, b->d_eob + L.base, b->d_energy + L.base,
+                                                      b->d_dist + 2 * (size_t)L.base, s);
+        if (rc) {
+            (void)hipStreamSynchronize(s);  // earlier launches of this flush still read the pinned descriptors' device copy
+            return rc;
         }
     }
-    const size_t total = base;
-    if (hipMemcpyAsync(b->h_eob, b->d_eob, 2 * total, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(b->h_energy, b->d_energy, 8 * total, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipMemcpyAsync(b->h_dist, b->d_dist, 16 * total, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    for (size_t i = 0; i < total; i++) b->results[b->launch_handle[i]].coeff_offset = (uint32_t)i;  // position in the output arrays for now
+    if (hipMemcpyAsync(b->h_out, b->d_out, 26 * (size_t)b->max_cand, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return SVTHIP_ERR_DEVICE;
     for (size_t hnd = 0; hnd < b->cands.size(); hnd++) {
         svthip_tu_result& r = b->results[hnd];

@@ -126,9 +126,87 @@ void quantize(int log_scale, int highbd, const int32_t* coeff, intptr_t n, int32
     HOK(hipStreamSynchronize(s), "sync");
 }
 
+// TX_SIZES_ALL order of the reference's TxSize enum (Codec/EbDefinitions.h): squares, 2:1 rectangles, 4:1 rectangles
+const uint8_t kTxW[19] = {4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 4, 16, 8, 32, 16, 64};
+const uint8_t kTxH[19] = {4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 4, 32, 8, 64, 16};
+
+void inv_txfm_add8(int w, int h, const int32_t* input, uint8_t* output, int32_t stride, uint8_t tx_type)
+{
+    tls.init();
+    hipStream_t s = static_cast<hipStream_t>(svthip_stream(tls.ctx));
+    Arena a(tls.arena);
+    const int win = w > 32 ? 32 : w, hin = h > 32 ? 32 : h;
+    int32_t* d_in = a.take<int32_t>((size_t)win * hin);
+    uint8_t* d_rec = a.take<uint8_t>((size_t)w * h);
+    svthip_itxfm_desc* d_desc = a.take<svthip_itxfm_desc>(1);
+    svthip_itxfm_desc desc = {0, 0, (uint16_t)w, tx_type, 0};
+    HOK(hipMemcpyAsync(d_in, input, (size_t)win * hin * 4, hipMemcpyHostToDevice, s), "upload");
+    HOK(hipMemcpy2DAsync(d_rec, (size_t)w, output, (size_t)stride, (size_t)w, h, hipMemcpyHostToDevice, s), "upload");
+    HOK(hipMemcpyAsync(d_desc, &desc, sizeof(desc), hipMemcpyHostToDevice, s), "upload");
+    OK(svthip_inv_txfm2d_add_batch_dev(tls.ctx, d_in, d_desc, 1, w, h, 8, 0, d_rec, s), "svthip_inv_txfm2d_add_batch_dev");
+    HOK(hipMemcpy2DAsync(output, (size_t)stride, d_rec, (size_t)w, (size_t)w, h, hipMemcpyDeviceToHost, s), "download");
+    HOK(hipStreamSynchronize(s), "sync");
+}
+
+// one block against a search area: the block and the window rows it can touch go up packed (pitch = multiple of 4 with slack for the
+// kernel's aligned group loads), the one result comes back
+void sad_loop_one(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t height, uint32_t width, uint32_t raw,
+                  uint32_t sw, uint32_t sh, uint32_t* sad, int16_t* xy)
+{
+    tls.init();
+    hipStream_t s = static_cast<hipStream_t>(svthip_stream(tls.ctx));
+    Arena a(tls.arena);
+    const uint32_t k = ref_stride / raw;                   // 1 or 2 (checked by the batch entry)
+    const uint32_t rows = (sh - 1) + (height - 1) * k + 1;  // window rows in units of the raw stride
+    const uint32_t wcols = sw + width - 1;
+    const uint32_t pitch = (wcols + 64 + 3) & ~3u, spitch = (width + 3) & ~3u;
+    uint8_t* d_src = a.take<uint8_t>((size_t)spitch * height + 64);
+    uint8_t* d_ref = a.take<uint8_t>((size_t)pitch * (rows + 1) + 64);
+    svthip_sad_loop_desc* d_desc = a.take<svthip_sad_loop_desc>(1);
+    uint32_t* d_sad = a.take<uint32_t>(1);
+    int16_t* d_xy = a.take<int16_t>(2);
+    const svthip_sad_loop_desc desc = {0, 0};
+    HOK(hipMemcpy2DAsync(d_src, spitch, src, src_stride, width, height, hipMemcpyHostToDevice, s), "upload");
+    HOK(hipMemcpy2DAsync(d_ref, pitch, ref, raw, wcols, rows, hipMemcpyHostToDevice, s), "upload");
+    HOK(hipMemcpyAsync(d_desc, &desc, sizeof(desc), hipMemcpyHostToDevice, s), "upload");
+    HOK(hipStreamSynchronize(s), "sync");  // `desc` lives on this stack frame
+    OK(svthip_sad_loop_batch_dev(tls.ctx, d_src, spitch, d_ref, k * pitch, pitch, d_desc, 1, width, height, sw, sh, d_sad, d_xy, s), "svthip_sad_loop_batch_dev");
+    HOK(hipMemcpyAsync(sad, d_sad, 4, hipMemcpyDeviceToHost, s), "download");
+    HOK(hipMemcpyAsync(xy, d_xy, 4, hipMemcpyDeviceToHost, s), "download");
+    HOK(hipStreamSynchronize(s), "sync");
+}
+
 }  // namespace
 
 extern "C" {
+
+void svthip_av1_inv_txfm_add(const int32_t* dqcoeff, uint8_t* dst, int32_t stride, const svthip_txfm_param* p)
+{
+    static_assert(sizeof(svthip_txfm_param) == 24, "TxfmParam layout");
+    if (!p || p->tx_size >= 19) die("svthip_av1_inv_txfm_add: bad TxfmParam");
+    if (p->lossless) die("svthip_av1_inv_txfm_add: lossless (Walsh-Hadamard) blocks are not provided");
+    inv_txfm_add8(kTxW[p->tx_size], kTxH[p->tx_size], dqcoeff, dst, stride, p->tx_type);
+}
+
+uint32_t svthip_nxm_sad_kernel(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t height, uint32_t width)
+{
+    uint32_t sad = 0;
+    int16_t xy[2];
+    sad_loop_one(src, src_stride, ref, ref_stride, height, width, ref_stride, 1, 1, &sad, xy);
+    return sad;
+}
+
+void svthip_sad_loop_kernel(uint8_t* src, uint32_t src_stride, uint8_t* ref, uint32_t ref_stride, uint32_t height, uint32_t width, uint64_t* best_sad,
+                            int16_t* x_search_center, int16_t* y_search_center, uint32_t src_stride_raw, int16_t search_area_width,
+                            int16_t search_area_height)
+{
+    uint32_t sad = 0;
+    int16_t xy[2] = {0, 0};
+    sad_loop_one(src, src_stride, ref, ref_stride, height, width, src_stride_raw, (uint32_t)search_area_width, (uint32_t)search_area_height, &sad, xy);
+    *best_sad = sad;
+    *x_search_center = xy[0];
+    *y_search_center = xy[1];
+}
 
 #define DEF_FWD(W, H)                                                                                                                   \
     void svthip_av1_fwd_txfm2d_##W##x##H(int16_t* input, int32_t* output, uint32_t input_stride, uint8_t transform_type, uint8_t bit_depth) \

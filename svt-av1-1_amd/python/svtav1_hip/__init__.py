@@ -53,6 +53,10 @@ def lib() -> C.CDLL:
     L.svthip_stream.argtypes = [C.c_void_p]
     L.svthip_synchronize.restype = C.c_int32
     L.svthip_synchronize.argtypes = [C.c_void_p]
+    L.svthip_set_option.restype = C.c_int32
+    L.svthip_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.svthip_reserve.restype = C.c_int32
+    L.svthip_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32]
     L.svthip_me_fullpel_search.restype = C.c_int32
     L.svthip_me_fullpel_search.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t,
                                            C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -154,6 +158,10 @@ def lib() -> C.CDLL:
     return L
 
 
+OPT_SADLOOP_GENERIC = 0
+OPT_CONVOLVE_VALU = 1
+
+
 class SvtHipError(RuntimeError):
     pass
 
@@ -187,6 +195,13 @@ class Context:
 
     def synchronize(self):
         _check(lib().svthip_synchronize(self._h))
+
+    def set_option(self, option: int, value: int):
+        """svthip_set_option: kernel-selection override of this context (OPT_SADLOOP_GENERIC / OPT_CONVOLVE_VALU)."""
+        _check(lib().svthip_set_option(self._h, option, value))
+
+    def reserve(self, width: int, height: int, n_pu: int = 85, n_jobs: int = 1, host_forms: bool = False):
+        _check(lib().svthip_reserve(self._h, width, height, n_pu, n_jobs, int(host_forms)))
 
     # -- host-pointer form (numpy in / numpy out) ------------------------------------------------
     def fullpel_search(self, src_plane: np.ndarray, ref_plane: np.ndarray, desc: np.ndarray):

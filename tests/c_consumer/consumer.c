@@ -36,6 +36,24 @@ _Static_assert(sizeof(svthip_quant_desc) == 16 && offsetof(svthip_quant_desc, n_
 _Static_assert(sizeof(svthip_txfm_desc) == 12 && sizeof(svthip_itxfm_desc) == 12, "svthip_txfm_desc / svthip_itxfm_desc");
 _Static_assert(sizeof(svthip_tu_desc) == 32 && offsetof(svthip_tu_desc, src_stride) == 20 && offsetof(svthip_tu_desc, tx_type) == 28, "svthip_tu_desc");
 
+/* The reference's TxfmParam as its header declares it (Codec/EbDefinitions.h:725-737; TxType / TxSize / TxSetType are one-byte packed
+ * enums), restated so that the host compiler decides the layout svthip_txfm_param must coincide with. */
+typedef struct {
+    uint8_t tx_type;
+    uint8_t tx_size;
+    int32_t lossless;
+    int32_t bd;
+    int32_t is_hbd;
+    uint8_t tx_set_type;
+    int32_t eob;
+} HostTxfmParam;
+_Static_assert(sizeof(HostTxfmParam) == sizeof(svthip_txfm_param) && sizeof(svthip_txfm_param) == 24 &&
+                   offsetof(HostTxfmParam, bd) == offsetof(svthip_txfm_param, bd) && offsetof(HostTxfmParam, eob) == offsetof(svthip_txfm_param, eob) &&
+                   offsetof(svthip_txfm_param, eob) == 20, "TxfmParam layout");
+_Static_assert(sizeof(svthip_recon_picture) == 48 && offsetof(svthip_recon_picture, stride_y) == 24 && offsetof(svthip_recon_picture, sample_bytes) == 44,
+               "svthip_recon_picture");
+_Static_assert(sizeof(svthip_xfer) == 32 && offsetof(svthip_xfer, offset) == 16, "svthip_xfer");
+
 /* The reference's MeCuResults_t as its header declares it (Codec/EbMotionEstimationLcuResults.h:56-76), restated here so that the
  * compiler that would build the reference decides the layout: svthip_me_cu_result_ref must coincide with it field by field. */
 typedef struct {
@@ -59,9 +77,10 @@ _Static_assert(offsetof(HostMeCuResults, distortionDirection) == offsetof(svthip
 
 enum {
     TAG_DIMS = 1, TAG_CUR, TAG_REF0, TAG_REF1, TAG_PARAMS, TAG_FP_DESC, TAG_TU_SRC, TAG_TU_PRED, TAG_TU_DESC, TAG_TU_QP, TAG_TU_ISCAN, TAG_TU_DIMS,
-    TAG_TX_RES, TAG_TX_COEFFQ, TAG_TX_QROW, TAG_TX_SCAN, TAG_TX_ISCAN, TAG_TX_PRED, TAG_FP_DESC_SMALL,
+    TAG_TX_RES, TAG_TX_COEFFQ, TAG_TX_QROW, TAG_TX_SCAN, TAG_TX_ISCAN, TAG_TX_PRED, TAG_FP_DESC_SMALL, TAG_ITX_COEFF, TAG_ITX_PRED, TAG_ITX_TYPE,
+    TAG_SAD_BLOCK,
     OUT_FP_SAD = 100, OUT_FP_MV, OUT_ME, OUT_TU_RECON, OUT_TU_Q, OUT_TU_EOB, OUT_TX_FWD, OUT_TX_INV, OUT_TX_Q, OUT_TX_DQ, OUT_TX_EOB, OUT_THREADS,
-    OUT_TU_DIST, OUT_ME209, OUT_OIS_GEN_CAND, OUT_OIS_GEN_TOTAL, OUT_OIS_I_CAND, OUT_OIS_I_TOTAL
+    OUT_TU_DIST, OUT_ME209, OUT_OIS_GEN_CAND, OUT_OIS_GEN_TOTAL, OUT_OIS_I_CAND, OUT_OIS_I_TOTAL, OUT_ITX_RECON, OUT_SAD
 };
 
 typedef struct { uint32_t tag; uint64_t bytes; void *data; } Section;
@@ -257,6 +276,43 @@ int main(int argc, char **argv)
         svthip_av1_inv_txfm2d_add_16x16(dq, pred, 24, 0 /* DCT_DCT */, 8);
         put(fo, OUT_TX_INV, pred, sec(TAG_TX_PRED)->bytes);
         free(pred);
+    }
+
+    /* 4b. av1_inv_txfm_add: the pointer Av1InvTransformRecon8bit calls (8-bit plane, TxfmParam), every one of the 19 transform sizes.
+     *     Inputs per size: 1024 int32 of packed dequantised coefficients, a 64 x 80 uint8 prediction tile, one tx_type. */
+    {
+        const int32_t *co = (const int32_t *)sec(TAG_ITX_COEFF)->data;
+        const uint8_t *ty = (const uint8_t *)sec(TAG_ITX_TYPE)->data;
+        uint8_t *tiles = (uint8_t *)malloc(sec(TAG_ITX_PRED)->bytes);
+        memcpy(tiles, sec(TAG_ITX_PRED)->data, sec(TAG_ITX_PRED)->bytes);
+        for (int ts = 0; ts < 19; ts++) {
+            HostTxfmParam hp;
+            memset(&hp, 0, sizeof(hp));
+            hp.tx_type = ty[ts];
+            hp.tx_size = (uint8_t)ts;
+            hp.bd = 8;
+            hp.is_hbd = 1;
+            hp.eob = 1024;
+            svthip_av1_inv_txfm_add(co + 1024 * ts, tiles + (size_t)ts * 64 * 80, 80, (const svthip_txfm_param *)(const void *)&hp);
+        }
+        put(fo, OUT_ITX_RECON, tiles, sec(TAG_ITX_PRED)->bytes);
+        free(tiles);
+    }
+
+    /* 4c. leaf SAD pointers: NxMSadKernel (one SAD) and SadLoopKernel (search area, full rows and the HME callers' skipped rows) */
+    {
+        uint8_t *blk = (uint8_t *)sec(TAG_SAD_BLOCK)->data; /* 128 x 128 plane: source block at (8,8), search grid origin at (16,24) */
+        uint64_t best[2];
+        int16_t xy[4];
+        uint32_t res[7];
+        res[0] = svthip_nxm_sad_kernel(blk + 8 * 128 + 8, 128, blk + 24 * 128 + 16, 128, 16, 16);
+        res[1] = svthip_nxm_sad_kernel(blk + 8 * 128 + 8, 256, blk + 24 * 128 + 16, 256, 16, 32); /* every other row of a 32 x 32 block */
+        svthip_sad_loop_kernel(blk + 8 * 128 + 8, 128, blk + 24 * 128 + 16, 128, 16, 16, &best[0], &xy[0], &xy[1], 128, 33, 33);
+        svthip_sad_loop_kernel(blk + 8 * 128 + 8, 256, blk + 24 * 128 + 16, 256, 8, 16, &best[1], &xy[2], &xy[3], 128, 24, 12);
+        res[2] = (uint32_t)best[0]; res[3] = (uint32_t)(uint16_t)xy[0] | ((uint32_t)(uint16_t)xy[1] << 16);
+        res[4] = (uint32_t)best[1]; res[5] = (uint32_t)(uint16_t)xy[2] | ((uint32_t)(uint16_t)xy[3] << 16);
+        res[6] = 0;
+        put(fo, OUT_SAD, res, sizeof(res));
     }
 
     /* 5. two threads, two contexts, different search areas (64x64 vs the 16x9 descriptors): the per-kernel LDS limit is process state */

@@ -17,9 +17,9 @@ CDIR = os.path.join(ROOT, "tests", "c_consumer")
 EXE = os.path.join(CDIR, "consumer")
 
 T = dict(DIMS=1, CUR=2, REF0=3, REF1=4, PARAMS=5, FP_DESC=6, TU_SRC=7, TU_PRED=8, TU_DESC=9, TU_QP=10, TU_ISCAN=11, TU_DIMS=12, TX_RES=13,
-         TX_COEFFQ=14, TX_QROW=15, TX_SCAN=16, TX_ISCAN=17, TX_PRED=18, FP_DESC_SMALL=19)
+         TX_COEFFQ=14, TX_QROW=15, TX_SCAN=16, TX_ISCAN=17, TX_PRED=18, FP_DESC_SMALL=19, ITX_COEFF=20, ITX_PRED=21, ITX_TYPE=22, SAD_BLOCK=23)
 O = dict(FP_SAD=100, FP_MV=101, ME=102, TU_RECON=103, TU_Q=104, TU_EOB=105, TX_FWD=106, TX_INV=107, TX_Q=108, TX_DQ=109, TX_EOB=110, THREADS=111,
-         TU_DIST=112, ME209=113, OIS_GEN_CAND=114, OIS_GEN_TOTAL=115, OIS_I_CAND=116, OIS_I_TOTAL=117)
+         TU_DIST=112, ME209=113, OIS_GEN_CAND=114, OIS_GEN_TOTAL=115, OIS_I_CAND=116, OIS_I_TOTAL=117, ITX_RECON=118, SAD=119)
 
 
 def test_header_compiles_as_c99_and_layouts_hold():
@@ -77,12 +77,24 @@ def test_c_consumer_end_to_end(tmp_path, oracle):
     scan = np.ascontiguousarray(tables.scan_pool[so:so + 256]); iscan = np.ascontiguousarray(tables.iscan_pool[so:so + 256])
     coeffq = rng.laplace(0, 300, 256).astype(np.int32)
     txpred = rng.integers(0, 256, (16, 24)).astype(np.uint16)
+    # av1_inv_txfm_add inputs: per transform size a packed coefficient block, a 64 x 80 prediction tile and a defined tx_type
+    itx_coeff = np.zeros((19, 1024), np.int32)
+    itx_pred = rng.integers(0, 256, (19, 64, 80)).astype(np.uint8)
+    itx_type = np.zeros(19, np.uint8)
+    for ts, (tw, th) in enumerate(svtav1_hip.TX_SIZES_WH):
+        n = min(tw, 32) * min(th, 32)
+        itx_coeff[ts, :n] = (rng.laplace(0, 60, n) * (rng.random(n) < 0.3)).astype(np.int32)
+        itx_coeff[ts, 0] = 900 - 100 * ts
+        types = svtav1_hip.valid_tx_types(tw, th)
+        itx_type[ts] = types[(3 * ts) % len(types)]
+    sad_plane = rng.integers(0, 256, (128, 128)).astype(np.uint8)
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     _write(inp, [(T["DIMS"], np.array([w, h], np.uint32)), (T["CUR"], pics[0].full), (T["REF0"], pics[1].full), (T["REF1"], pics[2].full),
                  (T["PARAMS"], bytes(P)), (T["FP_DESC"], desc), (T["FP_DESC_SMALL"], desc_small),
                  (T["TU_SRC"], tb["src"]), (T["TU_PRED"], tb["pred"]), (T["TU_DESC"], tb["desc"]), (T["TU_QP"], tb["qparams"]),
                  (T["TU_ISCAN"], tb["iscan"]), (T["TU_DIMS"], np.array([16, 16, tb["src"].size, tb["qparams"].shape[0], len(tb["desc"]) * 256], np.uint32)),
-                 (T["TX_RES"], res), (T["TX_COEFFQ"], coeffq), (T["TX_QROW"], qrow), (T["TX_SCAN"], scan), (T["TX_ISCAN"], iscan), (T["TX_PRED"], txpred)])
+                 (T["TX_RES"], res), (T["TX_COEFFQ"], coeffq), (T["TX_QROW"], qrow), (T["TX_SCAN"], scan), (T["TX_ISCAN"], iscan), (T["TX_PRED"], txpred),
+                 (T["ITX_COEFF"], itx_coeff), (T["ITX_PRED"], itx_pred), (T["ITX_TYPE"], itx_type), (T["SAD_BLOCK"], sad_plane)])
     r = subprocess.run([EXE, inp, outp], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     got = _read(outp)
@@ -132,5 +144,23 @@ def test_c_consumer_end_to_end(tmp_path, oracle):
     wr = txpred.copy()
     g(odq.ctypes.data, wr.ctypes.data, 24, 16, 16, 0, 8)
     assert np.array_equal(np.frombuffer(got[O["TX_INV"]], np.uint16).reshape(16, 24), wr)
+    # 4b. av1_inv_txfm_add (8-bit plane, TxfmParam) for all 19 sizes: the oracle reconstructs the widened tile like av1_inv_txfm_add_c does
+    got_itx = np.frombuffer(got[O["ITX_RECON"]], np.uint8).reshape(19, 64, 80)
+    for ts, (tw, th) in enumerate(svtav1_hip.TX_SIZES_WH):
+        wide = itx_pred[ts].astype(np.uint16)
+        g(itx_coeff[ts].ctypes.data, wide.ctypes.data, 80, tw, th, int(itx_type[ts]), 8)
+        assert np.array_equal(got_itx[ts], wide.astype(np.uint8)), (tw, th)
+        assert not np.array_equal(got_itx[ts][:th, :tw], itx_pred[ts][:th, :tw]), (tw, th)
+        assert np.array_equal(got_itx[ts][th:], itx_pred[ts][th:]) and np.array_equal(got_itx[ts][:, tw:], itx_pred[ts][:, tw:])
+    # 4c. leaf SAD pointers vs the oracle's restatement of the reference's C kernels
+    sres = np.frombuffer(got[O["SAD"]], np.uint32)
+    u8p = C.POINTER(C.c_uint8)
+    P8 = lambda a, off: C.cast(a.ctypes.data + off, u8p)   # noqa: E731
+    assert sres[0] == oracle.lib.orc_nxm_sad(P8(sad_plane, 8 * 128 + 8), 128, P8(sad_plane, 24 * 128 + 16), 128, 16, 16)
+    assert sres[1] == oracle.lib.orc_nxm_sad(P8(sad_plane, 8 * 128 + 8), 256, P8(sad_plane, 24 * 128 + 16), 256, 16, 32)
+    for k, (ss, rs, hh, ww, raw, sw_, sh_) in enumerate(((128, 128, 16, 16, 128, 33, 33), (256, 256, 8, 16, 128, 24, 12))):
+        bs, bx, by = C.c_uint64(0), C.c_int16(0), C.c_int16(0)
+        oracle.lib.orc_sad_loop_kernel(P8(sad_plane, 8 * 128 + 8), ss, P8(sad_plane, 24 * 128 + 16), rs, hh, ww, C.byref(bs), C.byref(bx), C.byref(by), raw, sw_, sh_)
+        assert sres[2 + 2 * k] == bs.value and sres[3 + 2 * k] == (bx.value & 0xffff) | ((by.value & 0xffff) << 16), k
     # 5. two threads x two contexts with different search areas: every iteration reproduced the single-threaded result
     assert np.frombuffer(got[O["THREADS"]], np.int32).tolist() == [0, 0]

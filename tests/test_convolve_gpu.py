@@ -58,12 +58,11 @@ def test_convolve_every_block_size(hip_ctx, oracle, size):
     bad = np.argwhere(got != want)
     assert bad.size == 0, (size, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
     if w % 32 == 0 and h % 32 == 0:   # these sizes run on the matrix cores; the VALU kernel must agree on them as well
-        import os
-        os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+        hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 1)
         try:
             got2 = _run(hip_ctx, src, S, dst, D, desc, w, h)
         finally:
-            del os.environ["SVTHIP_CONVOLVE_VALU"]
+            hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 0)
         assert np.array_equal(got2, want), size
 
 
@@ -184,12 +183,11 @@ def test_convolve_compound_every_block_size(hip_ctx, oracle, size):
     bad = np.argwhere(got != want)
     assert bad.size == 0, (size, bad[:5], got[tuple(bad[0])], want[tuple(bad[0])])
     if w % 32 == 0 and h % 32 == 0:
-        import os
-        os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+        hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 1)
         try:
             got2 = _run_compound(hip_ctx, s0, S0, s1, S1, dst, D, desc, w, h)
         finally:
-            del os.environ["SVTHIP_CONVOLVE_VALU"]
+            hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 0)
         assert np.array_equal(got2, want), size
 
 
@@ -236,12 +234,12 @@ def test_convolve_1080p_all_blocks_two_kernels_and_oracle_sample(hip_ctx, oracle
         return out.cpu().numpy().reshape(n, 64, 64)
 
     got = {k: run(k) for k in (False, True)}
-    os.environ["SVTHIP_CONVOLVE_VALU"] = "1"
+    hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 1)
     try:
         for k in (False, True):
             assert np.array_equal(run(k), got[k]), "matrix-core and VALU kernels differ (compound=%s)" % k
     finally:
-        del os.environ["SVTHIP_CONVOLVE_VALU"]
+        hip_ctx.set_option(svtav1_hip.OPT_CONVOLVE_VALU, 0)
     flat = pics[0].full.reshape(-1)
     for j in np.nonzero(ph == 0)[0][:200]:
         o = int(d["src_offset"][j])

@@ -79,12 +79,11 @@ def test_sad_loop_shapes(hip_ctx, oracle, case):
     if kind == "flat":
         assert (got[1] == 0).all() and (got[0] == 0).all()
     if w in (4, 8, 16, 32, 64):  # these widths take the packed-SAD kernel; the generic kernel must agree on them as well
-        import os
-        os.environ["SVTHIP_SADLOOP_GENERIC"] = "1"
+        hip_ctx.set_option(svtav1_hip.OPT_SADLOOP_GENERIC, 1)
         try:
             got2 = _run(hip_ctx, cur, ref, desc, w, h, sw, sh, k)
         finally:
-            del os.environ["SVTHIP_SADLOOP_GENERIC"]
+            hip_ctx.set_option(svtav1_hip.OPT_SADLOOP_GENERIC, 0)
         assert np.array_equal(got2[0], want[0]) and np.array_equal(got2[1], want[1])
 
 

@@ -1,9 +1,10 @@
 """Multi-GPU data path on the HIP side, as far as one GPU box can show it:
   * the HIP ME of a SHARD (svthip_motion_estimate_batch_dev on a contiguous SB range) equals the same rows of the unsharded HIP
     result, for every shard of 2-, 3- and 8-way partitions, 85 and 209 PUs;
-  * two real ranks (two processes sharing the one GPU, gloo for the collective because RCCL refuses two ranks on one device) run
-    svtav1_hip.sharded -- the code the RCCL path runs -- with the HIP compute, and every rank ends with the unsharded result;
-  * the recon exchange's device half: slabs written into a device plane, HIP border padding, equals the padded picture."""
+  * two real ranks (two processes sharing the one GPU; the transfers of svthip_me_gather_plan go over gloo because RCCL refuses two
+    ranks on one device) run svtav1_hip.sharded with the HIP compute, and every rank ends with the unsharded result;
+  * the C ABI's exchange entries at world 1 (svthip_comm_create / svthip_recon_exchange_dev / svthip_me_gather_results_dev through
+    sharded.Comm / ReconExchange): Y, Cb, Cr device planes holding every rank's slab come back padded like PadRefAndSetFlags."""
 import os
 import socket
 
@@ -66,8 +67,8 @@ def _rank_worker(rank, world, port, w, h, out_path):
     ctx = svtav1_hip.Context(0)
     d_pool = torch.from_numpy(pool).to("cuda:0")
     dev_compute = sharded.device_me_compute(ctx, d_pool.data_ptr(), [descs[0]], [descs[1]], [descs[2]], P, n_pu=85)
-    sme = sharded.ShardedMotionEstimation(w, h, granularity="sb")
-    full = sme.run(lambda sb_xy, n: dev_compute(sb_xy, n).cpu(), gather=True)   # HIP compute, gloo gather (one GPU for both ranks)
+    sme = sharded.ShardedMotionEstimation(w, h)
+    full = sme.run(lambda sb_xy, n: dev_compute(sb_xy, n).cpu(), gather=True)   # HIP compute, planned transfers over gloo (one GPU for both ranks)
     np.save(out_path.format(rank=rank), full.numpy())
     ctx.close()
     dist.barrier()
@@ -90,29 +91,49 @@ def test_two_ranks_hip_compute_shared_gather_code(hip_ctx, tmp_path):
 
 
 @pytest.mark.parametrize("case", [(1920, 1080, 160, 1, 8), (3840, 2160, 160, 2, 8), (960, 540, 80, 1, 3)])
-def test_recon_slabs_then_hip_padding(hip_ctx, case):
-    """What every rank does after the all-gather: the slabs of all ranks sit in its device plane, svthip_pad_plane_dev completes the
-    reference picture (PadRefAndSetFlags).  The slab geometry is ReconExchange's (SB-row slabs)."""
+def test_recon_exchange_entry_world1_all_slabs_then_padding(hip_ctx, case):
+    """svthip_recon_exchange_dev through sharded.ReconExchange with a world-1 svthip_comm: the slabs of all (virtual) ranks -- geometry
+    from ReconExchange's own row table for `world` ranks -- sit in the device planes Y, Cb, Cr; the entry pads all three like
+    PadRefAndSetFlags.  (At world 1 the RCCL group is empty; the transfer lists themselves are executed by tests/test_sharding_gloo.py.)"""
     torch = pytest.importorskip("torch")
-    w, h, pad, sb_, world = case
-    dt = np.uint8 if sb_ == 1 else np.uint16
+    w, h, pad, es, world = case
+    dt = np.uint8 if es == 1 else np.uint16
     rng = np.random.default_rng(w)
-    picture = rng.integers(0, 256 if sb_ == 1 else 1024, (h, w)).astype(dt)
-    stride = w + 2 * pad
-    plane = torch.full(((h + 2 * pad) * stride * sb_,), 0x77, dtype=torch.uint8, device="cuda:0")
-    host = np.full((h + 2 * pad, stride), 0x7777 if sb_ == 2 else 0x77, dt)
-    covered = 0
-    for r in range(world):
-        ex = sharded.ReconExchange.__new__(sharded.ReconExchange)
-        nx = (w + 63) // 64
-        first, count = sharded.shard_sb_range(w, h, world, r, "row")
-        y0 = (first // nx) * 64
-        y1 = min(h, (first // nx + count // nx) * 64)
-        host[pad + y0:pad + y1, pad:pad + w] = picture[y0:y1]
-        covered += y1 - y0
-    assert covered == h
-    plane.copy_(torch.from_numpy(host.view(np.uint8).reshape(-1)))
-    hip_ctx.pad_plane_dev(plane.data_ptr(), stride, w, h, pad, pad, sb_)
-    hip_ctx.synchronize()
-    got = plane.cpu().numpy().view(dt).reshape(h + 2 * pad, stride)
-    assert np.array_equal(got, np.pad(picture, pad, mode="edge"))
+    geo = [(w, h, pad), (w // 2, h // 2, pad // 2), (w // 2, h // 2, pad // 2)]
+    truth = [rng.integers(0, 256 if es == 1 else 1024, (gh, gw)).astype(dt) for gw, gh, _ in geo]
+    rows = [sharded.recon_slab_rows(h, world, r) for r in range(world)]
+    assert sum(n for _, n in rows) == h and rows[0][0] == 0
+    host = []
+    for (gw, gh, gp), pic in zip(geo, truth):
+        a = np.full((gh + 2 * gp, gw + 2 * gp), 0x7777 if es == 2 else 0x77, dt)
+        sub = 0 if gw == w else 1
+        for y0, n in rows:   # every rank's slab written where that rank would have reconstructed it
+            a[gp + (y0 >> sub):gp + ((y0 + n) >> sub), gp:gp + gw] = pic[y0 >> sub:(y0 + n) >> sub]
+        host.append(a)
+    planes = [torch.from_numpy(a.view(np.uint8).copy()).to("cuda:0") for a in host]
+    comm = sharded.Comm(hip_ctx)
+    try:
+        ex = sharded.ReconExchange(w, h, pad, comm=comm, sample_bytes=es)
+        assert ex.world == 1 and ex.my_rows == (0, h)
+        ex.exchange(planes)
+        hip_ctx.synchronize()
+    finally:
+        comm.close()
+    for p, (gw, gh, gp), pic in zip(planes, geo, truth):
+        assert np.array_equal(p.cpu().numpy().view(dt), np.pad(pic, gp, mode="edge"))
+
+
+def test_me_gather_entry_world1(hip_ctx):
+    """svthip_me_gather_results_dev at world 1: the local [n_jobs][n][record] rows land in the full array (a strided device copy)."""
+    torch = pytest.importorskip("torch")
+    comm = sharded.Comm(hip_ctx)
+    try:
+        local = torch.randint(0, 255, (3, 28, 85, 24), dtype=torch.uint8, device="cuda:0")
+        full = torch.zeros_like(local)
+        comm.me_gather_results_dev(local.data_ptr(), full.data_ptr(), 3, 28, 85 * 24)
+        hip_ctx.synchronize()
+        assert torch.equal(local, full)
+        sme = sharded.ShardedMotionEstimation(448, 200, comm=comm)
+        assert (sme.first, sme.count, sme.n_total) == (0, 28, 28)
+    finally:
+        comm.close()
