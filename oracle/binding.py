@@ -409,7 +409,7 @@ class ReferenceME:
         assert rc == 0
         return b, h, j
 
-    def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0, all_pu=False):
+    def run(self, cur, ref0, ref1, params, two_lists=False, hierarchical_levels=3, asm_type=0, all_pu=False, resolution_4k=False):
         """cur/ref0/ref1: svtav1_hip.synth.PaPicture; params: svtav1_hip.MeParams.
         all_pu: the 209-PU mode (NPU = 209, else 85)
         -> dict(sad [n,2,NPU], mv [n,2,NPU], origin [n,2,2], res [n,NPU,11])"""
@@ -433,7 +433,7 @@ class ReferenceME:
                        P.hme_level2_search_area_in_height_array[0], P.hme_level2_search_area_in_height_array[1],
                        P.enable_hme_flag, P.enable_hme_level0_flag, P.enable_hme_level1_flag, P.enable_hme_level2_flag,
                        int(two_lists), P.temporal_layer_index, hierarchical_levels, P.is_used_as_reference_flag, 0,
-                       10, 10 if P.ref_poc_equal else 20, asm_type, int(all_pu)], dtype=np.int32)
+                       10, 10 if P.ref_poc_equal else 20, asm_type, int(all_pu), int(resolution_4k)], dtype=np.int32)
         n = ((w + 63) // 64) * ((h + 63) // 64)
         npu = 209 if all_pu else 85
         sad = np.zeros((n, 2, npu), np.uint32)

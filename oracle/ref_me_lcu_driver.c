@@ -59,7 +59,7 @@ enum {
     IP_SEARCH_W, IP_SEARCH_H, IP_NHME_W, IP_NHME_H, IP_L0_TOTAL_W, IP_L0_TOTAL_H,
     IP_L0_W0, IP_L0_W1, IP_L0_H0, IP_L0_H1, IP_L1_W0, IP_L1_W1, IP_L1_H0, IP_L1_H1, IP_L2_W0, IP_L2_W1, IP_L2_H0, IP_L2_H1,
     IP_EN_HME, IP_EN_L0, IP_EN_L1, IP_EN_L2, IP_TWO_LISTS, IP_TEMPORAL_LAYER, IP_HIER_LEVELS, IP_IS_REF, IP_USE_SUBPEL,
-    IP_REF0_POC, IP_REF1_POC, IP_ASM_TYPE, IP_ALL_PU, IP_COUNT
+    IP_REF0_POC, IP_REF1_POC, IP_ASM_TYPE, IP_ALL_PU, IP_RES_4K, IP_COUNT
 };
 
 /* planes: [0]=current, [1]=list-0 reference, [2]=list-1 reference; each {full, quarter, sixteenth}.
@@ -89,7 +89,8 @@ int ref_me_lcu_run(uint8_t **planes, int width, int height, const int32_t *ip, u
     scs->luma_width = (uint16_t)width;
     scs->luma_height = (uint16_t)height;
     scs->sb_sz = 64;
-    scs->input_resolution = (width * height < INPUT_SIZE_1080i_TH) ? INPUT_SIZE_576p_RANGE_OR_LOWER : INPUT_SIZE_1080p_RANGE;
+    scs->input_resolution = ip[IP_RES_4K] ? INPUT_SIZE_4K_RANGE  /* a crop of a 3840x2160 sequence keeps its sequence's resolution class */
+                           : (width * height < INPUT_SIZE_1080i_TH) ? INPUT_SIZE_576p_RANGE_OR_LOWER : INPUT_SIZE_1080p_RANGE;
     scs->static_config.rate_control_mode = 0;
     EbObjectWrapper_t *scs_wr = (EbObjectWrapper_t *)calloc(1, sizeof(*scs_wr));
     scs_wr->objectPtr = scs;

@@ -66,6 +66,28 @@ def me_chain209_fixture():
                         mv=out["mv"], origin=out["origin"], res=out["res"])
 
 
+def me_chain_4k_fixture():
+    """BASELINE configs[4]: MotionEstimateLcu (sub-pel off) with the 4K parameter set (set_me_hme_params_oq resolution index 4:
+    HME level 0 = 128 x 80 total, Codec/EbMotionEstimationProcess.c:94-156) and input_resolution = INPUT_SIZE_4K_RANGE on a 448 x 256
+    crop of a 3840 x 2160 synthetic sequence (pan (22, 9) / (-31, -14) samples: beyond the 64 x 64 full-pel area, so the hierarchical
+    levels decide), B pictures of two pyramids -- 5 levels / layer 1 (350 % level-0 area) and 4 levels / layer 2 (100 %) -- plus a
+    base-layer picture of the 5-level pyramid (525 %, list 1 = zero centre); 85 and 209 PUs."""
+    refme = ReferenceME()
+    w, h = 448, 256
+    big = synth.synth_luma(3840, 2160, 4)
+    x0, y0 = 1700, 900
+    imgs = [np.ascontiguousarray(big[y0 + dy:y0 + dy + h, x0 + dx:x0 + dx + w]) for dx, dy in ((0, 0), (22, 9), (-31, -14))]
+    pics = [synth.PaPicture(x) for x in imgs]
+    out = {}
+    for name, hl, tl in (("h5t1", 5, 1), ("h4t2", 4, 2), ("h5t0", 5, 0)):
+        P = svtav1_hip.default_me_params(3840, 2160, hl, tl)
+        for npu in (85, 209):
+            r = refme.run(pics[0], pics[1], pics[2], P, two_lists=True, hierarchical_levels=hl, all_pu=(npu == 209), resolution_4k=True)
+            for k in ("sad", "mv", "origin", "res"):
+                out[f"{name}_{npu}_{k}"] = r[k]
+    np.savez_compressed(os.path.join(HERE, "me_lcu_4k_crop.npz"), cur=imgs[0], ref0=imgs[1], ref1=imgs[2], **out)
+
+
 def interp_fixture():
     refme = ReferenceME()
     img = np.random.default_rng(7).integers(0, 256, (160, 224), dtype=np.uint8)
@@ -344,6 +366,11 @@ def subpel_search_fixture():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # regenerate only the named fixtures: python tests/golden/make_golden.py me_chain_4k
+        for name in sys.argv[1:]:
+            globals()[name + "_fixture"]()
+        sys.exit(0)
+    me_chain_4k_fixture()
     subpel_search_fixture()
     bipred_frac_fixture()
     ois_fixture()

@@ -105,6 +105,55 @@ def test_hip_me_chain209_matches_golden(hip_ctx):
     _check_chain209(res, ls, lm, g)
 
 
+_CASES_4K = [("h5t1", 5, 1), ("h4t2", 4, 2), ("h5t0", 5, 0)]
+
+
+def _check_4k(res, ls, lm, g, name, n_pu):
+    for l in (0, 1):
+        assert np.array_equal(ls[l], g[f"{name}_{n_pu}_sad"][:, l]) and np.array_equal(lm[l], g[f"{name}_{n_pu}_mv"][:, l]), (name, n_pu, l)
+    r = g[f"{name}_{n_pu}_res"]
+    assert np.array_equal(res["totalMeCandidateIndex"], r[:, :, 8])
+    for f, c in (("xMvL0", 0), ("yMvL0", 1), ("xMvL1", 2), ("yMvL1", 3)):
+        assert np.array_equal(res[f], r[:, :, c]), (name, n_pu, f)
+    for k, (di, dr) in enumerate(((4, 5), (6, 7), (9, 10))):
+        assert np.array_equal(res["distortion"][:, :, k], r[:, :, di].astype(np.uint32)) and np.array_equal(res["direction"][:, :, k], r[:, :, dr]), (name, n_pu, k)
+
+
+@pytest.mark.parametrize("n_pu", [85, 209])
+@pytest.mark.parametrize("case", _CASES_4K)
+def test_oracle_me_chain_4k_parameter_set_matches_golden(oracle, case, n_pu):
+    """BASELINE configs[4]: the reference's MotionEstimateLcu with the 4K parameter set and resolution class on a crop of a 3840 x 2160
+    sequence (tests/golden/make_golden.py::me_chain_4k_fixture) vs the oracle chain."""
+    from me_chain_util import oracle_me_picture
+    name, hl, tl = case
+    g = _load("me_lcu_4k_crop.npz")
+    pics = [synth.PaPicture(g[k]) for k in ("cur", "ref0", "ref1")]
+    P = svtav1_hip.default_me_params(3840, 2160, hl, tl)
+    assert (P.hme_level0_total_search_area_width, P.hme_level0_total_search_area_height) == (128, 80)
+    res, per = oracle_me_picture(oracle, pics, P, True, use_subpel=False, n_pu=n_pu)
+    for l in (0, 1):
+        assert np.array_equal(per[l][0][:, 2:4], g[f"{name}_{n_pu}_origin"][:, l])
+    _check_4k(res, [per[0][1], per[1][1]], [per[0][2], per[1][2]], g, name, n_pu)
+    # the pan is outside the 64 x 64 full-pel area around the zero vector: the hierarchical levels found it
+    if tl > 0:
+        o = g[f"{name}_{n_pu}_origin"]
+        assert np.median(o[:, 0, 0] + 32) == -22 and np.median(o[:, 0, 1] + 32) == -9 and np.median(o[:, 1, 0] + 32) == 31
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pu", [85, 209])
+@pytest.mark.parametrize("case", _CASES_4K)
+def test_hip_me_chain_4k_parameter_set_matches_golden(hip_ctx, case, n_pu):
+    pytest.importorskip("torch")
+    from me_chain_util import device_me_picture
+    name, hl, tl = case
+    g = _load("me_lcu_4k_crop.npz")
+    pics = [synth.PaPicture(g[k]) for k in ("cur", "ref0", "ref1")]
+    P = svtav1_hip.default_me_params(3840, 2160, hl, tl)
+    res, ls, lm = device_me_picture(hip_ctx, pics, P, True, use_subpel=False, n_pu=n_pu)
+    _check_4k(res, ls, lm, g, name, n_pu)
+
+
 def test_oracle_fullpel209_matches_golden(oracle):
     g = _load("fullpel_209pu.npz")
     cur, ref = synth.PaPicture(g["cur"]), synth.PaPicture(g["ref"])
