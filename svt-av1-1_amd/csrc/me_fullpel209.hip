@@ -13,7 +13,10 @@ namespace fp209 {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 3) fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
+#ifndef SVTHIP_FP209_MIN_WAVES
+#define SVTHIP_FP209_MIN_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, SVTHIP_FP209_MIN_WAVES) fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                                             const uint8_t* __restrict__ ref_plane, uint32_t ref_stride,
                                                             const int32_t* __restrict__ desc, uint32_t n_sb, uint32_t* __restrict__ out_sad,
                                                             uint32_t* __restrict__ out_mv)
@@ -21,7 +24,13 @@ __global__ void __launch_bounds__(256, 3) fullpel209_kernel(const uint8_t* __res
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t sb = xcd_item(blockIdx.x, n_sb);  // raster neighbours share an XCD's L2 (me_kernels.h)
     if (sb >= n_sb) return;
-    fp209::fullpel209_sb(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
+    // wave-uniform choice of the search-loop form (me_fullpel209_impl.h): clipped windows at the picture's left / right edge take the general one
+#ifdef SVTHIP_FP209_EXPERIMENT_FAST_ONLY  // resource experiments: tools/kernel_resources.sh ... -DSVTHIP_FP209_EXPERIMENT_FAST_ONLY
+    fp209::fullpel209_sb<true>(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
+    return;
+#endif
+    if ((desc[6 * sb + 4] & 15) == 0) fp209::fullpel209_sb<true>(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
+    else fp209::fullpel209_sb<false>(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
 }
 
 size_t fullpel209_lds_bytes(uint32_t max_sh) { return (size_t)fp209::kFp209Fixed + (size_t)(max_sh + 63) * SVTHIP_FULLPEL_LDS_PITCH; }

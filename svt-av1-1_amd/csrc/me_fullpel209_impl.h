@@ -110,6 +110,11 @@ __device__ const Fp209SlotTable kFp209SlotOfPu = fp209_make_slot_table();
 // d: the superblock's descriptor (6 int32: src_offset, ref_offset, x/y search origin, search width/height), any address space;
 // smem: kFp209Fixed + (sh + 63) * SVTHIP_FULLPEL_LDS_PITCH bytes of workgroup LDS, 16-byte aligned.
 // Results go to out_sad / out_mv [209 * sbi ...] in ME-buffer order.  Must be called by all 256 threads.
+// FAST (search width a multiple of 16, the usual case): every position of every item is inside the area and idx = idx0 | i with idx0 = the
+// lane's y * 128 + 16 * xg, so the keys are formed with the position's NUMBER i as an inline constant -- min over i of (sad << k | i) --
+// and idx0 is OR-ed in once per tracker before the lanes are reduced (the bits of idx0, i and the SAD are disjoint, so the order of two
+// keys of one lane is unchanged).  No idx registers: 16 fewer live VGPRs.  Otherwise positions outside the area carry idx = ~0.
+template <bool FAST>
 __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                              const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* d, uint32_t sbi,
                                              uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv, uint8_t* smem)
@@ -137,6 +142,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     const int xo = __builtin_amdgcn_readfirstlane(d[2]), yo = __builtin_amdgcn_readfirstlane(d[3]);
     const int sw = __builtin_amdgcn_readfirstlane(d[4]), sh = __builtin_amdgcn_readfirstlane(d[5]);
     const int n_xg = (sw + 15) >> 4;
+    const uint32_t inv_xg = (65536u + (uint32_t)n_xg - 1u) / (uint32_t)n_xg;  // wave-uniform, scalar unit
 
     // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
     {
@@ -184,10 +190,15 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     const int n_iter = (n_items + 63) >> 6;
 
     for (int it = 0; it < n_iter; it++) {
+        // an opaque copy of the lane number, renewed every iteration: every per-lane LDS address below is formed from it INSIDE the loop
+        // (one or two adds each).  Formed from `lane` they are loop-invariant, get hoisted, and at the 168-register limit of three
+        // workgroups per CU the hoisted copies are what the register allocator spills and reloads around the search loop.
+        uint32_t lane_v = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_v));
         int pg = it * 64 + lane;
         const bool lane_valid = pg < n_items;
         if (!lane_valid) pg = 0;
-        const int y = pg / n_xg;
+        const int y = (int)(((uint32_t)pg * inv_xg) >> 16);  // pg / n_xg, exact for n_xg <= 8 and pg < 1024 (the emulated division is ~20 instructions)
         const int xg = pg - y * n_xg;
 
         // per-position raster index; positions outside the search area get idx = ~0 so that every key
@@ -195,26 +206,29 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
         // per-lane slot addresses of the tracker groups (byte addresses in LDS; the group offset goes into the instruction).
         // Formed inside the loop from an opaque copy of the lane number: hoisted out of the loop they would sit in VGPRs that the
         // kernel does not have (it runs at the 168-register limit of three workgroups per CU)
-        uint32_t lane_v = (uint32_t)lane;
-        asm volatile("" : "+v"(lane_v));
         const uint32_t slot16 = key_lds + 4 * (lane_v & 15);        // + 4 * (64Q + 16zz) or + 4 * 288
         const uint32_t slot8 = key_lds + 4 * (lane_v & 7) + 32 * Q;  // + 4 * 256
 
+        // A lane past the last item repeats item 0: its keys duplicate lane 0's of the first pass and change no minimum (the 64x64 PU
+        // and the 32x16[5] recurrence, which are not plain minima, check lane_valid).
         uint32_t idx[16];
+        const uint32_t idx0 = (uint32_t)(y * 128 + 16 * xg);
+        const uint32_t orv = FAST ? idx0 : 0u;  // what a finished tracker still has to be OR-ed with
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int x = 16 * xg + i;
-            idx[i] = (lane_valid && x < sw) ? (uint32_t)(y * 128 + x) : 0xffffffffu;
-        }
-
+        for (int i = 0; i < 16; i++) idx[i] = FAST ? (uint32_t)i : ((lane_valid && 16 * xg + i < sw) ? idx0 + (uint32_t)i : 0xffffffffu);
         uint32_t s16lo[4][4], s16hi[4][4];  // [zz][q] packed u16 16x16 sums
-        uint64_t hrow[2][4];     // [part][q] 16x8 sums of the left 16x16 of the current row of 16x16s, kept for 32x8
-        uint64_t hcol[2][2][4];  // [C][side][q] 8x16 sums of the upper row of 16x16s, kept for 8x32
+        // 32x8 / 8x32 pair a 16x8 / 8x16 of this block with the one of the block to its left / above.  Only the TOP 16x8 and the LEFT
+        // 8x16 of the earlier block are kept; its bottom / right sums are its 16x16 sum (kept anyway) minus them -- packed u16 halves
+        // never borrow because each part is <= the whole.  24 fewer live VGPRs for 32 more subtractions per item, which is what takes
+        // the kernel's search loop out of scratch memory at the 168-register limit of three workgroups per CU.
+        uint64_t hrow_top[4];     // [q] top 16x8 sums of the left 16x16 of the current row of 16x16s
+        uint64_t hcol_lef[2][4];  // [C][q] left 8x16 sums of the upper row of 16x16s
 
         const uint8_t* wbase = win + (y + 32 * Qy) * kPitch + 16 * xg + 32 * Qx;
 
         // software-pipelined row steps, as in me_fullpel_impl.h: the window row and source row of step n + 1 are requested before the
         // 16 v_qsad of step n
+#ifdef SVTHIP_FP209_PIPELINE
         uint4 An, Bn;
         uint32_t Sn[4];
         {
@@ -223,6 +237,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 #pragma unroll
             for (int h = 0; h < 4; h++) Sn[h] = src4[h];
         }
+#endif
 #pragma unroll
         for (int zz = 0; zz < 4; zz++) {
             const int C = zz & 1, R = zz >> 1;
@@ -230,10 +245,19 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 
 #pragma unroll
             for (int r8 = 0; r8 < 8; r8++) {
+#ifndef SVTHIP_FP209_PIPELINE  // operands loaded where they are used: the 85-PU kernel's software pipelining (next step's window row and
+                                // source row requested one step ahead) costs 16 more live VGPRs, which here means spills: 764 vs 723 us per 6120 SBs
+                const uint8_t* pp_ = wbase + (16 * R + 2 * r8) * kPitch + 16 * C;
+                const uint4 A = *reinterpret_cast<const uint4*>(pp_), B = *reinterpret_cast<const uint4*>(pp_ + 16);
+                const uint32_t* sr_ = src4 + (16 * R + 2 * r8) * sstride4 + 4 * C;
+                const uint32_t S[4] = {sr_[0], sr_[1], sr_[2], sr_[3]};
+#else
                 const uint4 A = An, B = Bn;
                 const uint32_t S[4] = {Sn[0], Sn[1], Sn[2], Sn[3]};
+#endif
                 asm volatile("" ::"v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), "s"(S[0]), "s"(S[1]), "s"(S[2]), "s"(S[3]));
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef SVTHIP_FP209_PIPELINE
                 {
                     const int nstep = zz * 8 + r8 + 1;
                     if (nstep < 32) {
@@ -247,6 +271,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
                 // window dword pairs (W[k], W[k+1]), k = 0..6: the even ones are the loaded register pairs, the odd ones are formed
                 // with one v_pk_mov_b32 each (hi of one pair, lo of the next).  Left to the compiler they cost two v_mov each
                 // and, under register pressure (209-PU kernel), a round trip through scratch memory.
@@ -271,65 +296,62 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             uint32_t k8[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, k16 = 0xffffffffu;
             uint32_t k16x8[2] = {0xffffffffu, 0xffffffffu}, k8x16[2] = {0xffffffffu, 0xffffffffu};
             uint32_t k32x8[2] = {0xffffffffu, 0xffffffffu}, k8x32[2] = {0xffffffffu, 0xffffffffu};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
-            const uint32_t c0 = quad_min_scatter<4>(k8[0], k8[1], k8[2], k8[3], lane);  // first part of the group reduction below
-
-            // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
+            // One position quad at a time, with a scheduling fence after each: left to itself the scheduler forms the ~200 keys of a 16x16
+            // block's 13 trackers all at once for the sake of instruction-level parallelism and spills the live 16x16 sums to make room.
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t lo = (uint32_t)acc[0][q] + (uint32_t)acc[1][q] + (uint32_t)acc[2][q] + (uint32_t)acc[3][q];
-                const uint32_t hi = (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32) +
-                                    (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32);
-                k16 = track4(k16, pack64(lo, hi), &idx[4 * q], himask);
-                s16lo[zz][q] = lo;
-                s16hi[zz][q] = hi;
-            }
-            // 16x8 (top / bottom halves) and 8x16 (left / right halves) of this 16x16: packed sums of two 8x8 (<= 16320)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+                for (int k = 0; k < 4; k++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
+                // 16x8 (top / bottom halves) and 8x16 (left / right halves) of this 16x16: packed sums of two 8x8 (<= 16320);
+                // 16x16 = top + bottom (packed u16, no carry between halves: <= 4 * 8160)
                 const uint64_t top = pack64((uint32_t)acc[0][q] + (uint32_t)acc[1][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32));
                 const uint64_t bot = pack64((uint32_t)acc[2][q] + (uint32_t)acc[3][q], (uint32_t)(acc[2][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
                 const uint64_t lef = pack64((uint32_t)acc[0][q] + (uint32_t)acc[2][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[2][q] >> 32));
                 const uint64_t rig = pack64((uint32_t)acc[1][q] + (uint32_t)acc[3][q], (uint32_t)(acc[1][q] >> 32) + (uint32_t)(acc[3][q] >> 32));
+                const uint32_t lo = (uint32_t)top + (uint32_t)bot, hi = (uint32_t)(top >> 32) + (uint32_t)(bot >> 32);
+                k16 = track4(k16, pack64(lo, hi), &idx[4 * q], himask);
+                s16lo[zz][q] = lo;
+                s16hi[zz][q] = hi;
                 k16x8[0] = track4(k16x8[0], top, &idx[4 * q], himask);
                 k16x8[1] = track4(k16x8[1], bot, &idx[4 * q], himask);
                 k8x16[0] = track4(k8x16[0], lef, &idx[4 * q], himask);
                 k8x16[1] = track4(k8x16[1], rig, &idx[4 * q], himask);
                 // 32x8 = two 16x8 side by side (zz pairs (0,1), (2,3)); 8x32 = two 8x16 on top of each other (pairs (0,2), (1,3)); <= 32640
-                if (C == 0) { hrow[0][q] = top; hrow[1][q] = bot; }
+                if (C == 0) hrow_top[q] = top;
                 else {
-                    const uint64_t a0 = hrow[0][q], a1 = hrow[1][q];
+                    const uint64_t a0 = hrow_top[q];
+                    const uint64_t a1 = pack64(s16lo[zz - 1][q] - (uint32_t)a0, s16hi[zz - 1][q] - (uint32_t)(a0 >> 32));
                     k32x8[0] = track4(k32x8[0], pack64((uint32_t)a0 + (uint32_t)top, (uint32_t)(a0 >> 32) + (uint32_t)(top >> 32)),
                                               &idx[4 * q], himask);
                     k32x8[1] = track4(k32x8[1], pack64((uint32_t)a1 + (uint32_t)bot, (uint32_t)(a1 >> 32) + (uint32_t)(bot >> 32)),
                                               &idx[4 * q], himask);
                 }
-                if (R == 0) { hcol[C][0][q] = lef; hcol[C][1][q] = rig; }
+                if (R == 0) hcol_lef[C][q] = lef;
                 else {
-                    const uint64_t a0 = hcol[C][0][q], a1 = hcol[C][1][q];
+                    const uint64_t a0 = hcol_lef[C][q];
+                    const uint64_t a1 = pack64(s16lo[zz - 2][q] - (uint32_t)a0, s16hi[zz - 2][q] - (uint32_t)(a0 >> 32));
                     k8x32[0] = track4(k8x32[0], pack64((uint32_t)a0 + (uint32_t)lef, (uint32_t)(a0 >> 32) + (uint32_t)(lef >> 32)),
                                               &idx[4 * q], himask);
                     k8x32[1] = track4(k8x32[1], pack64((uint32_t)a1 + (uint32_t)rig, (uint32_t)(a1 >> 32) + (uint32_t)(rig >> 32)),
                                               &idx[4 * q], himask);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const uint32_t c0 = quad_min_scatter<4>(k8[0] | orv, k8[1] | orv, k8[2] | orv, k8[3] | orv, lane);  // first part of the group reduction below
             // publish this 16x16's trackers into slots 16 * (4Q + zz) + j
             {
                 constexpr uint32_t NONE = 0xffffffffu;
-                const uint32_t c1 = quad_min_scatter<4>(k16, k16x8[0], k16x8[1], k8x16[0], lane);
+                const uint32_t c1 = quad_min_scatter<4>(k16 | orv, k16x8[0] | orv, k16x8[1] | orv, k8x16[0] | orv, lane);
                 uint32_t r;
                 if (C == 1 && R == 1) {
-                    const uint32_t c2 = quad_min_scatter<4>(k8x16[1], k32x8[0], k32x8[1], k8x32[0], lane);
-                    const uint32_t c3 = quad_min_scatter<1>(k8x32[1], NONE, NONE, NONE, lane);
+                    const uint32_t c2 = quad_min_scatter<4>(k8x16[1] | orv, k32x8[0] | orv, k32x8[1] | orv, k8x32[0] | orv, lane);
+                    const uint32_t c3 = quad_min_scatter<1>(k8x32[1] | orv, NONE, NONE, NONE, lane);
                     r = row_min_from_quads<4>(c0, c1, c2, c3, lane);
                 } else if (C == 1 || R == 1) {
-                    const uint32_t c2 = quad_min_scatter<3>(k8x16[1], C == 1 ? k32x8[0] : k8x32[0], C == 1 ? k32x8[1] : k8x32[1], NONE, lane);
+                    const uint32_t c2 = quad_min_scatter<3>(k8x16[1] | orv, (C == 1 ? k32x8[0] : k8x32[0]) | orv, (C == 1 ? k32x8[1] : k8x32[1]) | orv, NONE, lane);
                     r = row_min_from_quads<3>(c0, c1, c2, NONE, lane);
                 } else {
-                    const uint32_t c2 = quad_min_scatter<1>(k8x16[1], NONE, NONE, NONE, lane);
+                    const uint32_t c2 = quad_min_scatter<1>(k8x16[1] | orv, NONE, NONE, NONE, lane);
                     r = row_min_from_quads<3>(c0, c1, c2, NONE, lane);
                 }
                 const uint32_t a = slot16 + 256 * Q;
@@ -354,6 +376,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                     k32x16[k] = track4(k32x16[k], pack64(r32x16lo[k][q], r32x16hi[k][q]), &idx[4 * q], himask);
                 k16x32[k] = track4(k16x32[k], pack64(r16x32lo[k][q], r16x32hi[k][q]), &idx[4 * q], himask);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // 32x32 = sum of the four 16x16: pairs are added packed (<= 2*32640 fits u16), then widened
@@ -378,52 +401,27 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 
         {
             // PU 92 (32x16[5], Q == 2) follows the recurrence instead: its tracker was never updated and stays 0xffffffff
-            const uint32_t g[8] = {k32, k32x16[0], k32x16[1], k16x32[0], k16x32[1], 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const uint32_t g[8] = {k32 | orv, k32x16[0] | orv, k32x16[1] | orv, k16x32[0] | orv, k16x32[1] | orv, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             ds_min_u32_off<4 * 256>(slot8, row_min_scatter<8, 5>(g, lane));
         }
 
-        // 64x64: exchange 32x32 sums between the four waves; wave Q finishes positions 4Q..4Q+3
-        __syncthreads();  // previous iteration's readers are done
-        {
-            // exchange layout [wave][uint4 index][lane][4]: 128-bit accesses of consecutive lanes are conflict-free (lane-major rows of
-            // 16 dwords put every second lane on the same banks)
-            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
-#pragma unroll
-            for (int q = 0; q < 4; q++) dst[q * 64] = make_uint4(s32acc[4 * q], s32acc[4 * q + 1], s32acc[4 * q + 2], s32acc[4 * q + 3]);
-        }
-        __syncthreads();
+        // Cross-quadrant PUs: wave Q finishes positions 4Q..4Q+3 of every lane's 16.  Two exchange rounds through the 16 KB buffer:
+        // round B moves the packed 32x16 sums (top / bottom half of every quadrant) -- 64x16 is their sum across a quadrant pair, and the
+        // 32x32 sums that 64x64 / 64x32 / 32x64 need are top + bottom of the same data, so no separate 32x32 round is needed (it was a
+        // third round with two more barriers per iteration); round C moves the packed 16x32 sums for 16x64.
         const int xbase = 16 * xg + 4 * Q;
         const uint32_t ibase = (uint32_t)(y * 128 + xbase);
         uint32_t cidx[4];  // idx of positions 4Q..4Q+3 (idx[] is indexed statically, so rebuilt from Q)
 #pragma unroll
-        for (int j = 0; j < 4; j++) cidx[j] = (lane_valid && xbase + j < sw) ? ibase + j : 0xffffffffu;
+        for (int j = 0; j < 4; j++) cidx[j] = FAST ? (uint32_t)j : ((lane_valid && xbase + j < sw) ? ibase + j : 0xffffffffu);
+        const uint32_t corv = FAST ? ibase : 0u;
         uint32_t kc[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, kd[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane); wave 2 also publishes 32x16[5] per position
+        __syncthreads();  // previous iteration's readers are done
         {
-            uint4 v[4];
-#pragma unroll
-            for (int w = 0; w < 4; w++) v[w] = *reinterpret_cast<const uint4*>(xch + w * 1024 + Q * 256 + lane * 4);
-            const uint32_t q0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, q1[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
-            const uint32_t q2[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, q3[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
-            uint32_t qbot[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t top = q0[j] + q1[j], bot = q2[j] + q3[j], lef = q0[j] + q2[j], rig = q1[j] + q3[j], all = top + bot;
-                // strict '<', positions visited in raster order per lane; positions outside the area never win
-                const bool better = (all < best64_raw) && cidx[j] != 0xffffffffu;
-                best64_raw = better ? all : best64_raw;
-                best64_idx = better ? cidx[j] : best64_idx;
-                kc[0] = min(kc[0], (top << 14) | cidx[j]);   // 64x32[0]   (<= 261120 < 2^18)
-                kc[1] = min(kc[1], (bot << 14) | cidx[j]);   // 64x32[1]
-                kc[2] = min(kc[2], (lef << 14) | cidx[j]);   // 32x64[0]
-                kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
-                qbot[j] = bot;                                       // 64x32[1] per position, for the 32x16[5] recurrence
-            }
-            *reinterpret_cast<uint4*>(qa + Q * 256 + lane * 4) = make_uint4(qbot[0], qbot[1], qbot[2], qbot[3]);  // [position quad][lane][4]
-        }
-        // ---- round B: 32x16 sums (packed u16, 2 PUs x 8 dwords per lane) -> 64x16; wave 2 also publishes 32x16[5] per position
-        __syncthreads();
-        {
-            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
+            // exchange layout [wave][uint4 index][lane][4]: 128-bit accesses of consecutive lanes are conflict-free (lane-major rows of
+            // 16 dwords put every second lane on the same banks)
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane_v * 4);
             dst[0] = make_uint4(r32x16lo[0][0], r32x16hi[0][0], r32x16lo[0][1], r32x16hi[0][1]);
             dst[64] = make_uint4(r32x16lo[0][2], r32x16hi[0][2], r32x16lo[0][3], r32x16hi[0][3]);
             dst[128] = make_uint4(r32x16lo[1][0], r32x16hi[1][0], r32x16lo[1][1], r32x16hi[1][1]);
@@ -431,7 +429,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             if (Q == 2) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    *reinterpret_cast<uint4*>(qv + q * 256 + lane * 4) =
+                    *reinterpret_cast<uint4*>(qv + q * 256 + lane_v * 4) =
                         make_uint4(r32x16lo[1][q] & 0xffffu, r32x16lo[1][q] >> 16, r32x16hi[1][q] & 0xffffu, r32x16hi[1][q] >> 16);
             }
         }
@@ -443,21 +441,36 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             for (int w = 0; w < 4; w++)
 #pragma unroll
                 for (int R = 0; R < 2; R++) {
-                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * R + (Q >> 1)) * 256 + lane * 4 + 2 * (Q & 1));
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * R + (Q >> 1)) * 256 + lane_v * 4 + 2 * (Q & 1));
                     pr[w][R][0] = t.x & 0xffffu; pr[w][R][1] = t.x >> 16; pr[w][R][2] = t.y & 0xffffu; pr[w][R][3] = t.y >> 16;
                 }
+            uint32_t qbot[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                kd[0] = min(kd[0], ((pr[0][0][j] + pr[1][0][j]) << 14) | cidx[j]);  // 64x16[0] = 32x16[0] + 32x16[2]
-                kd[1] = min(kd[1], ((pr[0][1][j] + pr[1][1][j]) << 14) | cidx[j]);  // 64x16[1] = 32x16[1] + 32x16[3]
-                kd[2] = min(kd[2], ((pr[2][0][j] + pr[3][0][j]) << 14) | cidx[j]);  // 64x16[2] = 32x16[4] + 32x16[6]
-                kd[3] = min(kd[3], ((pr[2][1][j] + pr[3][1][j]) << 14) | cidx[j]);  // 64x16[3] = 32x16[5] + 32x16[7]
+                const uint32_t t0 = pr[0][0][j] + pr[1][0][j], t1 = pr[0][1][j] + pr[1][1][j];  // 64x16[0], 64x16[1]
+                const uint32_t t2 = pr[2][0][j] + pr[3][0][j], t3 = pr[2][1][j] + pr[3][1][j];  // 64x16[2], 64x16[3]
+                const uint32_t top = t0 + t1, bot = t2 + t3;                                    // 64x32[0], 64x32[1]
+                const uint32_t lef = pr[0][0][j] + pr[0][1][j] + pr[2][0][j] + pr[2][1][j], all = top + bot, rig = all - lef;  // 32x64[0], [1]
+                // strict '<', positions visited in raster order per lane; positions outside the area never win
+                const bool better = (all < best64_raw) && (FAST ? lane_valid : cidx[j] != 0xffffffffu);
+                best64_raw = better ? all : best64_raw;
+                best64_idx = better ? (ibase + j) : best64_idx;
+                kc[0] = min(kc[0], (top << 14) | cidx[j]);   // 64x32[0]   (<= 261120 < 2^18)
+                kc[1] = min(kc[1], (bot << 14) | cidx[j]);   // 64x32[1]
+                kc[2] = min(kc[2], (lef << 14) | cidx[j]);   // 32x64[0]
+                kc[3] = min(kc[3], (rig << 14) | cidx[j]);   // 32x64[1]
+                kd[0] = min(kd[0], (t0 << 14) | cidx[j]);    // 64x16[0] = 32x16[0] + 32x16[2]
+                kd[1] = min(kd[1], (t1 << 14) | cidx[j]);    // 64x16[1] = 32x16[1] + 32x16[3]
+                kd[2] = min(kd[2], (t2 << 14) | cidx[j]);    // 64x16[2] = 32x16[4] + 32x16[6]
+                kd[3] = min(kd[3], (t3 << 14) | cidx[j]);    // 64x16[3] = 32x16[5] + 32x16[7]
+                qbot[j] = bot;                               // 64x32[1] per position, for the 32x16[5] recurrence
             }
+            *reinterpret_cast<uint4*>(qa + Q * 256 + lane_v * 4) = make_uint4(qbot[0], qbot[1], qbot[2], qbot[3]);  // [position quad][lane][4]
         }
         // ---- round C: 16x32 sums -> 16x64; meanwhile wave 0 resolves the 32x16[5] recurrence of this iteration
         __syncthreads();
         {
-            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane * 4);
+            uint4* dst = reinterpret_cast<uint4*>(xch + Q * 1024 + lane_v * 4);
             dst[0] = make_uint4(r16x32lo[0][0], r16x32hi[0][0], r16x32lo[0][1], r16x32hi[0][1]);
             dst[64] = make_uint4(r16x32lo[0][2], r16x32hi[0][2], r16x32lo[0][3], r16x32hi[0][3]);
             dst[128] = make_uint4(r16x32lo[1][0], r16x32hi[1][0], r16x32lo[1][1], r16x32hi[1][1]);
@@ -470,7 +483,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             for (int w = 0; w < 4; w++)
 #pragma unroll
                 for (int C = 0; C < 2; C++) {
-                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * C + (Q >> 1)) * 256 + lane * 4 + 2 * (Q & 1));
+                    const uint2 t = *reinterpret_cast<const uint2*>(xch + w * 1024 + (2 * C + (Q >> 1)) * 256 + lane_v * 4 + 2 * (Q & 1));
                     pc[w][C][0] = t.x & 0xffffu; pc[w][C][1] = t.x >> 16; pc[w][C][2] = t.y & 0xffffu; pc[w][C][3] = t.y >> 16;
                 }
 #pragma unroll
@@ -481,8 +494,8 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 ke[3] = min(ke[3], ((pc[1][1][j] + pc[3][1][j]) << 14) | cidx[j]);  // 16x64[3] = 16x32[3] + 16x32[7]
             }
             // the twelve cross-quadrant trackers of this wave's positions in one group (slots 288 + j)
-            const uint32_t g[16] = {kc[0], kc[1], kc[2], kc[3], kd[0], kd[1], kd[2], kd[3], ke[0], ke[1], ke[2], ke[3],
-                                    0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const uint32_t g[16] = {kc[0] | corv, kc[1] | corv, kc[2] | corv, kc[3] | corv, kd[0] | corv, kd[1] | corv, kd[2] | corv, kd[3] | corv,
+                                    ke[0] | corv, ke[1] | corv, ke[2] | corv, ke[3] | corv, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
             ds_min_u32_off<4 * 288>(slot16, row_min_scatter<16, 12>(g, lane));
         }
         if (Q == 0) {
@@ -492,7 +505,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             uint32_t av[16], vv[16];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint4 a4 = *reinterpret_cast<const uint4*>(qa + q * 256 + lane * 4), v4 = *reinterpret_cast<const uint4*>(qv + q * 256 + lane * 4);
+                const uint4 a4 = *reinterpret_cast<const uint4*>(qa + q * 256 + lane_v * 4), v4 = *reinterpret_cast<const uint4*>(qv + q * 256 + lane_v * 4);
                 av[4 * q] = a4.x; av[4 * q + 1] = a4.y; av[4 * q + 2] = a4.z; av[4 * q + 3] = a4.w;
                 vv[4 * q] = v4.x; vv[4 * q + 1] = v4.y; vv[4 * q + 2] = v4.z; vv[4 * q + 3] = v4.w;
             }
@@ -502,7 +515,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
 #pragma unroll
                 for (int i = 15; i >= 0; i--) {
                     const int rank = lane * 16 + i;
-                    const bool ok = idx[i] != 0xffffffffu && rank > last && av[i] < q5_raw;
+                    const bool ok = (FAST ? lane_valid : idx[i] != 0xffffffffu) && rank > last && av[i] < q5_raw;
                     cand = ok ? (((uint32_t)rank << 16) | vv[i]) : cand;
                 }
                 cand = wave_min_u32(cand);
@@ -511,10 +524,7 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
                 q5_raw = cand & 0xffffu;
                 // raster index of that position: the lane that owns it broadcasts its idx
                 const int owner = last >> 4, pos = last & 15;
-                uint32_t myidx = 0;
-#pragma unroll
-                for (int i = 0; i < 16; i++) myidx = (pos == i) ? idx[i] : myidx;
-                q5_idx = (uint32_t)__shfl((int)myidx, owner);
+                q5_idx = (uint32_t)__shfl((int)idx0, owner) + (uint32_t)pos;  // the owning lane's y * 128 + 16 * xg, plus the position
             }
         }
     }

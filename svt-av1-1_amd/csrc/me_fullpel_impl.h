@@ -81,6 +81,7 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
     const int xo = __builtin_amdgcn_readfirstlane(d[2]), yo = __builtin_amdgcn_readfirstlane(d[3]);
     const int sw = __builtin_amdgcn_readfirstlane(d[4]), sh = __builtin_amdgcn_readfirstlane(d[5]);
     const int n_xg = (sw + 15) >> 4;
+    const uint32_t inv_xg = (65536u + (uint32_t)n_xg - 1u) / (uint32_t)n_xg;  // wave-uniform, scalar unit
 
     // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
     {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
         int pg = it * 64 + lane;
         const bool lane_valid = pg < n_items;
         if (!lane_valid) pg = 0;
-        const int y = pg / n_xg;
+        const int y = (int)(((uint32_t)pg * inv_xg) >> 16);  // pg / n_xg, exact for n_xg <= 8 and pg < 1024 (the emulated division is ~20 instructions)
         const int xg = pg - y * n_xg;
 
         // per-position raster index; positions outside the search area get idx = ~0 so that every key

@@ -41,6 +41,10 @@ __host__ __device__ constexpr int subpel_plane_pitch(int cols) { return 4 * (((c
 struct Planes {
     lds_u8 *A, *B, *H, *J;
     int PA, PB;  // pitches (multiples of 4)
+    // byte distances B - A, H - B, J - H: plane_addr selects a plane by ADDING them under compares.  (Selecting among the four pointers
+    // with a chain of ?: was turned by the compiler into an indexed load from a private copy of this struct: 96 bytes of scratch and
+    // ~450 scratch_load sites in the kernel for what are four wave-uniform values.)
+    int dAB, dBH, dHJ;
 };
 
 // 8 bytes starting `s` bytes into the aligned dword at LDS address `qa`: three aligned dwords + two v_alignbyte
@@ -101,10 +105,10 @@ struct Ctx {
 // LDS byte address of plane p at search coordinates (x, y), and that plane's pitch
 __device__ __forceinline__ uint32_t plane_addr(const Planes& P, int p, int x, int y, int& pitch)
 {
-    const lds_u8* base = p == 0 ? (const lds_u8*)P.A : (p == 1 ? (const lds_u8*)P.B : (p == 2 ? (const lds_u8*)P.H : (const lds_u8*)P.J));
+    const int off = (p >= 1 ? P.dAB : 0) + (p >= 2 ? P.dBH : 0) + (p >= 3 ? P.dHJ : 0);
     pitch = p == 0 ? P.PA : P.PB;
     const int oy = p <= 1 ? 3 : 1, ox = p == 0 ? 3 : 1;
-    return (uint32_t)reinterpret_cast<uintptr_t>(base + (y + oy) * pitch + x + ox);
+    return (uint32_t)reinterpret_cast<uintptr_t>((const lds_u8*)P.A) + (uint32_t)(off + (y + oy) * pitch + x + ox);
 }
 
 // All PUs of one class, 16 chunks of 4 cells, chunks [8 * half, 8 * half + 8) on this wave: lane group g = lane >> 3 owns chunk
@@ -386,6 +390,9 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     P.B = P.A + ((P.PA * rows_a + 15) & ~15);
     P.H = P.B + ((P.PB * rows_a + 15) & ~15);
     P.J = P.H + ((P.PB * rows_h + 15) & ~15);
+    P.dAB = (P.PA * rows_a + 15) & ~15;
+    P.dBH = (P.PB * rows_a + 15) & ~15;
+    P.dHJ = (P.PB * rows_h + 15) & ~15;
 
     // ---- bounding box of the samples the PUs can touch: x in [bx - 1, bx + W + 1], y in [by - 1, by + H + 1] ----
     // Every wave computes it for itself (two independent coalesced loads per lane, a DPP / bpermute min-max over the wave): no LDS, no

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-LIB_PATH = os.path.join(_PKG_ROOT, "libsvtav1_hip.so")
+# SVTAV1_HIP_LIB: A/B tooling only (tools/kernel_times.py loads experimental builds of the library side by side)
+LIB_PATH = os.environ.get("SVTAV1_HIP_LIB") or os.path.join(_PKG_ROOT, "libsvtav1_hip.so")
 
 NUM_SQ_PU = 85
 MAX_SAD_VALUE = 128 * 128 * 255
