@@ -95,60 +95,72 @@ def zero_centred_desc(descs_cur, descs_ref, sb_xy, width, height):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N = 1 only): the reference's AVX2 kernels on the host cores
+# CPU baselines (rank 0, N = 1 only): the REFERENCE's own code (oracle/_ref, compiled from /root/reference in the build container; it
+# travels to the GPU box as built libraries) on the host cores.  They run in a CHILD process that the parent starts before it touches a
+# GPU (`--cpu-baseline-worker`): the child builds its own synthetic inputs with numpy, waits for one line on stdin, runs a bounded sample
+# of every leg (~30 s in total) and prints one JSON line.  Reported baselines, not targets.
 # ----------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(pool_host, stride, desc, seconds=12.0):
-    """Reference AVX2 kernels (oracle/_ref, timing baseline) driven like FullPelSearch_LCU on the host
-    cores, one thread per core over disjoint SB ranges; falls back to the repo's C port."""
-    from oracle.binding import Oracle, Reference
-
-    pool2d = pool_host[: (pool_host.size // stride) * stride].reshape(-1, stride)   # flat pool viewed with the full-plane stride
+def _host_cores():
     try:
-        ncores = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 16))  # the GPU box gives one GPU job a 16-CPU share
-    sample = desc[:510]
-    if Reference.available():
-        ref = Reference()
-        kind = "reference"
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))  # the GPU box gives one GPU job a 16-CPU share
 
-        def run(chunk):
-            ref.fullpel_search_batch(pool2d, pool2d, chunk, asm_type=1)
-    else:
-        orc = Oracle()
-        kind = "port"
 
-        def run(chunk):
-            orc.fullpel_search_batch(pool2d, pool2d, chunk)
+def _threads_rate(run_chunk, chunks, seconds):
+    """run_chunk(i) over len(chunks) threads (ctypes releases the GIL) until `seconds` have passed; returns units per second."""
+    done = [0] * len(chunks)
+    stop = time.perf_counter() + seconds
+
+    def worker(i):
+        while time.perf_counter() < stop:
+            done[i] += run_chunk(i)
+
     t0 = time.perf_counter()
-    n1 = 0
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(chunks))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return sum(done) / (time.perf_counter() - t0)
+
+
+def cpu_headline(ncores, seconds=8.0):
+    """Reference AVX2 kernels (timing baseline) driven like FullPelSearch_LCU, one thread per core over disjoint SB ranges; falls back
+    to the repo's C port when oracle/_ref is absent."""
+    import svtav1_hip
+    from oracle.binding import Oracle, Reference
+    from svtav1_hip import synth
+
+    pics = [synth.PaPicture(synth.synth_luma(W, H, t)) for t in (0, 1)]
+    pool, pd = svtav1_hip.build_picture_pool(pics)
+    stride = pd[0].full_stride
+    pool2d = pool[: (pool.size // stride) * stride].reshape(-1, stride)
+    sample = zero_centred_desc([pd[1]], [pd[0]], svtav1_hip.sb_origins(W, H), W, H)
+    if Reference.available():
+        eng, kind = Reference(), "reference"
+        run = lambda chunk: eng.fullpel_search_batch(pool2d, pool2d, chunk, asm_type=1)  # noqa: E731
+    else:
+        eng, kind = Oracle(), "port"
+        run = lambda chunk: eng.fullpel_search_batch(pool2d, pool2d, chunk)  # noqa: E731
+    t0, n1 = time.perf_counter(), 0
     while time.perf_counter() - t0 < seconds * 0.3:
         run(sample[:128])
         n1 += 128
     single = n1 / (time.perf_counter() - t0)
     chunks = np.array_split(sample, ncores)
-    done = [0] * ncores
-    stop = time.perf_counter() + seconds * 0.7
 
-    def worker(i):
-        while time.perf_counter() < stop:
-            run(chunks[i])
-            done[i] += len(chunks[i])
+    def run_chunk(i):
+        run(chunks[i])
+        return len(chunks[i])
 
-    t0 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(ncores)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    multi = sum(done) / (time.perf_counter() - t0)
-    return {"value": round(multi, 1), "unit": "blocks/s", "cores": ncores, "kind": kind,
-            "single_thread_value": round(single, 1),
+    multi = _threads_rate(run_chunk, chunks, seconds * 0.7)
+    return {"value": round(multi, 1), "unit": "blocks/s", "cores": ncores, "kind": kind, "single_thread_value": round(single, 1),
             "sample": f"picture 1 searched in picture 0 (510 SBs, 64x64 search, 85 PUs) repeated for ~{seconds:.0f} s; "
                       f"{'reference ASM_AVX2 kernels driven like FullPelSearch_LCU' if kind == 'reference' else 'repo C port (oracle)'}; "
                       f"{ncores} threads over disjoint SB ranges"}
 
 
-def cpu_sad_loop_baseline(seconds=4.0):
+def cpu_sad_loop_baseline(seconds=3.0):
     """configs[0] on the host: the reference's C SadLoopKernel (C_DEFAULT/EbComputeSAD_C.c:73-119; oracle/_ref) on 16x16 blocks of an
     856x480 picture, +-16 search (33x33 positions), single thread -- "reference C path on host CPU"."""
     from oracle.binding import Oracle, Reference
@@ -177,6 +189,143 @@ def cpu_sad_loop_baseline(seconds=4.0):
             "sample": f"{n} SadLoopKernel calls (16x16 block, 33x33 positions, 856x480 picture) in {dt:.1f} s through ctypes"}
 
 
+_ME_PICS = None
+
+
+def _me_one_picture(_):
+    from oracle.binding import ReferenceME
+
+    import svtav1_hip
+    P = svtav1_hip.default_me_params(W, H, 3, 1)
+    ReferenceME().run(_ME_PICS[0], _ME_PICS[1], _ME_PICS[2], P, two_lists=True, hierarchical_levels=3)
+    return 1
+
+
+def cpu_me_chain_baseline(ncores, seconds=6.0):
+    """me_chain_subpel.85pu_B_fullpel_only on the host: the reference's own MotionEstimateLcu (sub-pel off -- the sub-pel arm needs a
+    NASM-only symbol the image cannot assemble), every SB of a 1080p B picture, one PROCESS per core (the function keeps its
+    allocations in process-wide tables), whole pictures per process."""
+    global _ME_PICS
+    import multiprocessing as mp
+
+    from oracle.binding import ReferenceME
+    from svtav1_hip import synth
+    if not ReferenceME.available():
+        return None
+    _ME_PICS = [synth.PaPicture(synth.synth_luma(W, H, t)) for t in (1, 0, 2)]
+    with mp.get_context("fork").Pool(ncores) as pool:
+        pool.map(_me_one_picture, range(ncores))           # warm: libraries loaded, pages touched
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            n += sum(pool.map(_me_one_picture, range(ncores)))
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "1080p B pictures/s", "superblocks_per_s": round(n * 510 / dt, 1), "cores": ncores, "kind": "reference",
+            "sample": f"{n} pictures in {dt:.1f} s: the reference's MotionEstimateLcu (asm_type 0, use_subpel_flag 0, 85 PUs, two lists, HME on) for all "
+                      f"510 SBs of a 1080p picture, {ncores} processes x whole pictures"}
+
+
+def cpu_tq_baseline(ncores, seconds_per_size=1.5):
+    """tq_chain.frame_1080p on the host: the reference's C chain per TU (oracle/ref_bench_driver.c: ResidualKernel_c ->
+    Av1TransformTwoD_NxN_c -> aom_quantize_b*_c_II -> av1_inv_txfm2d_add_NxN_c), the same 1920x1088 frame of TUs, rows and scans as the
+    GPU leg, one thread per core over disjoint TU ranges."""
+    import ctypes as C
+
+    import svtav1_hip
+    so = os.path.join(ROOT, "oracle", "_ref", "libsvtref_bench.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    f = lib.ref_bench_tq_chain
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    z = np.load(os.path.join(ROOT, "tests", "golden", "quant_tables.npz"))
+    qrows = np.ascontiguousarray(z["rows_bd8_inter"][[20, 120, 200], 0, :])
+    rng = np.random.default_rng(3)
+    pic_w, pic_h = 1920, 1088
+    src = rng.integers(0, 256, pic_w * pic_h).astype(np.uint8)
+    noise = rng.laplace(0, 6, pic_w * pic_h)
+    pred = np.clip(src - noise, 0, 255).astype(np.uint8)
+    recon = np.zeros_like(pred)
+    out = {}
+    for n in (4, 8, 16, 32, 64):
+        ts = svtav1_hip.TX_SIZES_WH.index((n, n))
+        types = [t for t in (0, 3, 9) if t in svtav1_hip.valid_tx_types(n, n)]
+        isc = {t: int(z["scan_offsets"][int(z["scan_index"][ts, t])]) for t in types}
+        d, nc = tile_tu_desc(svtav1_hip, n, n, pic_w, pic_h, isc, types, 3, rng)
+        scan_ptrs, iscan_ptrs, keep = (C.c_void_p * 16)(), (C.c_void_p * 16)(), []
+        for t in types:
+            sc, isn = np.ascontiguousarray(z["scan_pool"][isc[t]:isc[t] + nc]), np.ascontiguousarray(z["iscan_pool"][isc[t]:isc[t] + nc])
+            keep += [sc, isn]
+            scan_ptrs[t], iscan_ptrs[t] = sc.ctypes.data, isn.ctypes.data
+        offs = np.ascontiguousarray(d["src_offset"].astype(np.uint32))
+        tt = np.ascontiguousarray(d["tx_type"].astype(np.uint8))
+        qi = np.ascontiguousarray(d["qparam_index"].astype(np.uint8))
+        bounds = np.linspace(0, len(d), ncores + 1).astype(int)
+
+        def run_chunk(i):
+            a, b = int(bounds[i]), int(bounds[i + 1])
+            f(src.ctypes.data, pred.ctypes.data, recon.ctypes.data, pic_w, offs[a:b].ctypes.data, tt[a:b].ctypes.data, qi[a:b].ctypes.data, b - a, n,
+              qrows.ctypes.data, scan_ptrs, iscan_ptrs)
+            return (b - a) * n * n
+
+        rate = _threads_rate(run_chunk, list(range(ncores)), seconds_per_size)
+        out[f"{n}x{n}"] = {"value": round(rate / 1e6, 2), "unit": "Mpixel/s", "cores": ncores, "kind": "reference",
+                           "sample": f"one 1920x1088 frame of {len(d)} {n}x{n} TUs repeated for ~{seconds_per_size} s, reference C chain "
+                                     "(ResidualKernel_c, Av1TransformTwoD_c, aom_quantize_b_c_II, av1_inv_txfm2d_add_c)"}
+    return out
+
+
+def cpu_convolve_baseline(ncores, seconds=3.0):
+    """convolve_8tap on the host: the reference's av1_convolve_2d_sr_c (and the x / y / copy forms) driven like av1_inter_prediction on 64x64
+    blocks at the 225 fractional phases, one thread per core."""
+    import ctypes as C
+
+    from svtav1_hip import synth
+    so = os.path.join(ROOT, "oracle", "_ref", "libsvtref_bench.so")
+    if not os.path.exists(so):
+        return None
+    lib = C.CDLL(so)
+    f = lib.ref_bench_convolve
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32]
+    pic = synth.PaPicture(synth.synth_luma(W, H, 1))
+    S = pic.stride
+    per = 450                                     # blocks per thread and call: two SB columns x 225 phases
+    i = np.arange(per * ncores)
+    blk, ph = i // 225, i % 225
+    src_off = ((68 + (blk // 30) * 64) * S + 68 + (blk % 30) * 64).astype(np.uint32)
+    mode = ((1 + ph % 15) | ((1 + ph // 15) << 4) | (((blk + ph) % 4) << 8) | (((blk // 3 + ph // 5) % 4) << 12)).astype(np.uint16)
+    dst = np.zeros((ncores, per * 4096), np.uint8)
+    dst_off = (np.arange(per) * 4096).astype(np.uint32)
+
+    def run_chunk(k):
+        f(pic.full.ctypes.data, S, dst[k].ctypes.data, 64, src_off[k * per:(k + 1) * per].ctypes.data, dst_off.ctypes.data,
+          mode[k * per:(k + 1) * per].ctypes.data, per, 64, 64)
+        return per * 4096
+
+    rate = _threads_rate(run_chunk, list(range(ncores)), seconds)
+    return {"value": round(rate / 1e6, 2), "unit": "Mpixel/s", "cores": ncores, "kind": "reference",
+            "sample": f"64x64 blocks of a 1080p frame at the 15 x 15 fractional phases, {per} blocks per call and thread for ~{seconds} s, reference C "
+                      "av1_convolve_2d_sr_c through oracle/ref_convolve_driver.c"}
+
+
+def cpu_baseline_worker_main():
+    """Child process of the N = 1 run (started before the parent initialises a GPU): waits for one line on stdin, then times the
+    reference on the host cores and prints one JSON line {leg: cpu_baseline}."""
+    if not sys.stdin.readline():
+        return 0
+    ncores = _host_cores()
+    out = {"headline": cpu_headline(ncores)}
+    for name, fn in (("sad_loop_480p", cpu_sad_loop_baseline), ("me_chain_subpel.85pu_B_fullpel_only", lambda: cpu_me_chain_baseline(ncores)),
+                     ("tq_chain", lambda: cpu_tq_baseline(ncores)), ("convolve_8tap", lambda: cpu_convolve_baseline(ncores))):
+        try:
+            out[name] = fn()
+        except Exception as e:  # a missing reference library must not cost the GPU numbers
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------------------------------------------------
@@ -190,9 +339,45 @@ def load_profile_json(name):
 
 def pmc_traffic_bytes(entry):
     """(2 x FETCH_SIZE + WRITE_SIZE) KB -> bytes per launch; FETCH_SIZE is doubled for gfx950 as MI355X_MICROARCH.md prescribes."""
-    if not entry:
+    if not entry or "FETCH_SIZE" not in entry or "WRITE_SIZE" not in entry:
         return None
     return round((2.0 * entry["FETCH_SIZE"] + entry["WRITE_SIZE"]) * 1024.0)
+
+
+_PMC = None
+
+
+def pmc_entry(kernel, which=-1, workgroup=None):
+    """Counter record of one kernel from profiles/r03_pmc_traffic.json (tools/run_r03_pmc_traffic.sh: separate rocprofv3 --pmc passes over
+    this very bench command).  Records of a kernel are sorted by grid size: which = -1 takes the largest launch, 0 the smallest;
+    `workgroup` filters on the workgroup size.  None when the profile has no such kernel."""
+    global _PMC
+    if _PMC is None:
+        _PMC = load_profile_json("r03_pmc_traffic.json") or {}
+    recs = _PMC.get(kernel)
+    if not recs:   # rocprofv3 prints namespaces and template arguments: take the first kernel whose name contains the given text
+        recs = next((v for k, v in sorted(_PMC.items()) if kernel in k), None)
+    if not recs:
+        return None
+    if workgroup is not None:
+        recs = [r for r in recs if r.get("workgroup") == workgroup]
+    return recs[which] if recs else None
+
+
+def counters(entry, ms, algorithmic_bytes):
+    """The counter-backed view of one launch: algorithmic bytes (stated in DESIGN.md), HBM-side traffic from the counters, what fraction of the
+    8 TB/s peak that traffic is at the duration measured LIVE in this run, and how busy the vector units were (SQ_ACTIVE_INST_VALU
+    quad-cycles x 4 over the 1024 SIMDs' share of GRBM_GUI_ACTIVE / 8 cycles)."""
+    out = {"algorithmic_bytes": int(algorithmic_bytes), "traffic_bytes": None, "frac_hbm_by_traffic": None, "valu_busy": None}
+    if not entry:
+        return out
+    t = pmc_traffic_bytes(entry)
+    if t is not None:
+        out["traffic_bytes"] = t
+        out["frac_hbm_by_traffic"] = round(t / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    if entry.get("GRBM_GUI_ACTIVE") and entry.get("SQ_ACTIVE_INST_VALU"):
+        out["valu_busy"] = round(4.0 * entry["SQ_ACTIVE_INST_VALU"] / (1024.0 * entry["GRBM_GUI_ACTIVE"] / 8.0), 3)
+    return out
 
 
 class EventTimer:
@@ -251,6 +436,43 @@ def leg_me_chain(ctx, torch, svtav1_hip, timer, pool, descs, params_b, d_sb, n_s
             ms = timer.ms(lambda: fn(pool.data_ptr(), curs, r0, refs1, params_b, d_sb.data_ptr(), n_sb, d_out.data_ptr(), subpel, 0, None, None,
                                      timer.stream), 5)
             out[f"{n_pu}pu_{name}"] = {"ms_per_picture": round(ms / n_jobs, 4), "superblocks_per_s": round(n_jobs * n_sb / ms * 1e3, 0)}
+    # the kernels of these chains one by one: live duration (HIP events on the launch stream), algorithmic bytes, counter traffic, VALU busy
+    n = n_jobs * n_sb
+    stride = descs[0].full_stride
+    d_desc = torch.zeros((n, 6), dtype=torch.int32, device=dev)
+    hme = lambda: ctx.hme_search_center_batch_dev(pool.data_ptr(), curs, r0, params_b, 0, d_sb.data_ptr(), n_sb, None, d_desc.data_ptr(), None, None,  # noqa: E731
+                                                  timer.stream)
+    P = params_b
+    l0w = [int(P.hme_level0_search_area_in_width_array[k] * P.hme_level0_multiplier_x // 100) for k in range(2)]
+    l0h = [int(P.hme_level0_search_area_in_height_array[k] * P.hme_level0_multiplier_y // 100) for k in range(2)]
+    # per SB: the three source blocks + per region the level-0 / 1 / 2 windows + five 64 x 32-row centre-check blocks + the descriptor
+    hme_bytes = 4096 + 1024 + 256 + sum((l0w[a] + 15) * (l0h[b] + 15) + (16 + 31) * (16 + 31) + (8 + 63) * (8 + 63) for a in range(2) for b in range(2)) \
+        + 5 * 2048 + 24
+    kern = {"hme_center_kernel": dict(ms=round(timer.ms(hme, 10), 4), **counters(pmc_entry("hme_center_kernel"), timer.ms(hme, 10), n * hme_bytes))}
+    for n_pu, fp, sub, wg, kfp in ((85, ctx.fullpel_search_dev, ctx.subpel_refine_dev, 512, "fullpel85_kernel"),
+                                   (209, ctx.fullpel_search209_dev, ctx.subpel_refine209_dev, 448, "fullpel209_kernel")):
+        d_sad = torch.empty((n, n_pu), dtype=torch.int32, device=dev)
+        d_mv = torch.empty_like(d_sad)
+        a = (pool.data_ptr(), stride, pool.data_ptr(), stride, d_desc.data_ptr(), n, SEARCH_W, SEARCH_H, d_sad.data_ptr(), d_mv.data_ptr())
+        run_fp = lambda: fp(*a, timer.stream)  # noqa: E731
+        ms_fp = timer.ms(run_fp, 10)
+        kern[kfp] = dict(ms=round(ms_fp, 4), frac_sad_ceiling=round(ABSDIFF_PER_BLOCK * n / (ms_fp * 1e-3) / VALU_PEAK_ABSDIFF_PER_S, 4),
+                         **counters(pmc_entry(kfp), ms_fp, n * (4096 + 127 * 127 + 8 * n_pu)))
+        torch.cuda.synchronize()
+        s0, m0 = d_sad.clone(), d_mv.clone()
+        with torch.cuda.stream(timer.tstream):
+            def restore():
+                d_sad.copy_(s0, non_blocking=True)
+                d_mv.copy_(m0, non_blocking=True)
+
+            def run_sub():   # the refinement is in place: restore the full-pel results first (timed separately and subtracted)
+                restore()
+                sub(pool.data_ptr(), stride, pool.data_ptr(), stride, d_desc.data_ptr(), n, SEARCH_W, SEARCH_H, d_sad.data_ptr(), d_mv.data_ptr(), False,
+                    timer.stream)
+            ms_sub = timer.ms(run_sub, 10) - timer.ms(restore, 10)
+        kern[f"subpel_planes_kernel_{n_pu}pu"] = dict(ms=round(ms_sub, 4), **counters(pmc_entry("subpel_planes_kernel", -1, wg), ms_sub,
+                                                                                       n * (4096 + 135 * 135 + 16 * n_pu)))
+    out["kernels_6120_superblocks"] = kern
     out["workload"] = "12 x 1080p pictures per call, 64x64 search area, HME on, sub-pel = half + quarter pel of every PU (SSD metric), bi-prediction"
     return out
 
@@ -292,7 +514,6 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
     out = {"workload": "fused per-TU encode chain, 8-bit; quantiser rows = av1_build_quantizer luma rows at qindex 20/120/200; "
                        "bytes/pixel algorithmic = 1 src + 1 pred + 1 recon + 4 qcoeff + 2 iscan = 9",
            "sizes": {}}
-    traffic = load_profile_json("r02_pmc_traffic_tq.json") or load_profile_json("r01_pmc_traffic_tq.json") or {}
     for n in (4, 8, 16, 32, 64):
         ts = svtav1_hip.TX_SIZES_WH.index((n, n))
         types = [t for t in (0, 3, 9) if t in svtav1_hip.valid_tx_types(n, n)]
@@ -315,12 +536,11 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
             ms = timer.ms(run, 20 if label == "frame_1080p" else 5)
             px = n_tu * n * n
             algo = px * 3 + n_tu * nc * 6 + n_tu * 2
+            # rocprofv3 names the instantiation "encode_tu_kernel<N, N, unsigned char>"; its two launches differ in grid size
+            rec = pmc_entry(f"encode_tu_kernel<{n}, {n}, unsigned char", 0 if label == "frame_1080p" else -1)
             res[label] = {"n_tu": n_tu, "ms": round(ms, 4), "gpix_per_s": round(px / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
-                          "frac_hbm": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+                          "frac_hbm_algorithmic": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4), **counters(rec, ms, algo)}
             del src, pred, recon, noise, d_q
-        key = f"encode_tu_kernel_{n}x{n}"
-        if key in traffic:
-            res["plane_64Mpx"]["traffic_bytes"] = pmc_traffic_bytes(traffic[key])
         out["sizes"][f"{n}x{n}"] = res
         torch.cuda.empty_cache()
     return out
@@ -343,9 +563,16 @@ def leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev):
     d_dst = torch.empty(n * 4096, dtype=torch.uint8, device=dev)
     ms = timer.ms(lambda: ctx.av1_convolve_sr_batch_dev(pool.data_ptr(), S, d_dst.data_ptr(), 64, d_desc.data_ptr(), n, 64, 64, timer.stream), 10)
     algo = n * (71 * 71 + 4096 + 16)
-    out = {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
-           "frac_hbm": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4),
-           "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per block"}
+    # The 225 phases of a block read the SAME 71 x 71 source samples: counted per (block, phase) the "algorithmic" bytes flatter the
+    # kernel by the cache reuse (round 2 quoted 0.39 of the HBM peak that way); the counters see the source once per block and the
+    # destination once per output, which is what frac_hbm_by_traffic reports.  unique_bytes = what has to cross HBM at least once.
+    unique = 510 * 71 * 71 + n * (4096 + 16)
+    out = {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2), "algorithmic_gbps_per_block_phase": round(algo / ms / 1e6, 1),
+           "unique_bytes": unique, "frac_hbm_unique": round(unique / ms / 1e6 / HBM_PEAK_GBPS, 4),
+           **counters(pmc_entry("av1_convolve_mfma_kernel<2, false>"), ms, algo),
+           "workload": "8-bit av1_convolve_2d_sr, 64x64 blocks x 225 phases over a 1080p frame; algorithmic bytes = 71 x 71 read + 4096 written per "
+                       "(block, phase); the source of a block is shared by its 225 phases (cache hits), so the HBM fraction that counts is "
+                       "frac_hbm_by_traffic"}
     # the BI_PRED form of the same blocks: list 0 from picture 1, list 1 from picture 2 with the phases swapped (av1_jnt_convolve_2d pair)
     c = np.zeros(n, dtype=svtav1_hip.CONVOLVE_COMPOUND_DESC_DTYPE)
     c["src0_offset"] = d["src_offset"]
@@ -358,8 +585,9 @@ def leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev):
     msc = timer.ms(lambda: ctx.av1_convolve_compound_batch_dev(pool.data_ptr(), S, pool.data_ptr(), S, d_dst.data_ptr(), 64, d_cdesc.data_ptr(), n, 64, 64,
                                                                timer.stream), 10)
     algoc = n * (2 * 71 * 71 + 4096 + 16)
-    out["compound_bipred"] = {"ms": round(msc, 4), "gpix_per_s": round(n * 4096 / msc / 1e6, 2), "algorithmic_gbps": round(algoc / msc / 1e6, 1),
-                              "frac_hbm": round(algoc / msc / 1e6 / HBM_PEAK_GBPS, 4)}
+    out["compound_bipred"] = {"ms": round(msc, 4), "gpix_per_s": round(n * 4096 / msc / 1e6, 2),
+                              "algorithmic_gbps_per_block_phase": round(algoc / msc / 1e6, 1),
+                              **counters(pmc_entry("av1_convolve_mfma_kernel<2, true>"), msc, algoc)}
     return out
 
 
@@ -384,6 +612,7 @@ def leg_sad_loop(ctx, torch, svtav1_hip, timer, dev):
     absdiff = n * 33 * 33 * 256
     return {"blocks": n, "ms": round(ms, 4), "blocks_per_s": round(n / ms * 1e3, 0), "absdiff_per_s": round(absdiff / ms * 1e3, 0),
             "frac_sad_ceiling": round(absdiff / ms * 1e3 / VALU_PEAK_ABSDIFF_PER_S, 4),
+            **counters(pmc_entry("sad_loop_qsad_kernel"), ms, n * (256 + 48 * 48 + 8)),
             "workload": "16x16 blocks, 33x33 positions (+-16), 856x480 8-bit, 12 pictures per launch, SadLoopKernel semantics (packed-SAD kernel: 8 positions per lane, v_qsad_pk_u16_u8)"}
 
 
@@ -461,6 +690,119 @@ def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):
         out[name] = {"blocks": n, "ms": round(ms, 4), "gpix_per_s": round(n * 4096 / ms / 1e6, 2)}
     out["workload"] = ("3840x2160: ME = search centres + 64x64 full-pel, 85 PUs, one list, 3 pictures per launch; T/Q = one 10-bit luma frame of TUs; "
                        "inter prediction = every 64x64 block x 8 phase pairs, 10-bit samples")
+    return out
+
+
+def leg_host_threads(svtav1_hip, seconds=2.0):
+    """What the reference's ME process would see through the HOST-pointer entry: T host threads (its ME process runs max(20, cores / 3)
+    of them, Codec/EbEncHandle.c:436-439), one context each, one 1080p P picture per call of svthip_motion_estimate_picture (upload of
+    two luma planes from pageable memory, planes derived on the device, the whole chain with sub-pel, MeCuResults_t rows back).
+    pictures/s for T = 1, 4, 20 beside the device-resident figure of the same chain."""
+    import ctypes as C
+
+    from svtav1_hip import synth
+    L = svtav1_hip.lib()
+
+    class HostPicture(C.Structure):
+        _fields_ = [("buffer_y", C.c_void_p), ("stride_y", C.c_uint32), ("origin_x", C.c_uint16), ("origin_y", C.c_uint16), ("width", C.c_uint16),
+                    ("height", C.c_uint16)]
+
+    L.svthip_motion_estimate_picture.restype = C.c_int32
+    L.svthip_motion_estimate_picture.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p]
+    pics = [synth.PaPicture(synth.synth_luma(W, H, t)) for t in (1, 0)]
+    P = svtav1_hip.default_me_params(W, H, 3, 0)
+    n_sb = 510
+    out = {}
+    for T in (1, 4, 20):
+        ctxs = [svtav1_hip.Context(0) for _ in range(T)]
+        for c in ctxs:
+            c.reserve(W, H, 85, 1, True)   # scratch sized once, as MeContextCtor sizes the reference's buffers
+        bufs = []
+        for _ in range(T):   # every thread owns its pictures and its result rows, like a picture control set
+            cur, ref = pics[0].full.copy(), pics[1].full.copy()
+            rows = np.zeros((n_sb, 85, 40), np.uint8)
+            ptrs = (C.c_void_p * n_sb)(*[rows.ctypes.data + i * 85 * 40 for i in range(n_sb)])
+            bufs.append((cur, ref, rows, ptrs, HostPicture(cur.ctypes.data, pics[0].stride, 68, 68, W, H),
+                         HostPicture(ref.ctypes.data, pics[1].stride, 68, 68, W, H)))
+        done = [0] * T
+        err = []
+
+        def worker(i, stop):
+            _, _, _, ptrs, hc, hr = bufs[i]
+            while time.perf_counter() < stop[0]:
+                rc = L.svthip_motion_estimate_picture(ctxs[i]._h, C.byref(hc), C.byref(hr), None, C.byref(P), 1, 0, 85, ptrs)
+                if rc:
+                    err.append(rc)
+                    return
+                done[i] += 1
+
+        for phase_s in (0.3, seconds):   # warm-up, then the timed phase
+            done[:] = [0] * T
+            stop = [time.perf_counter() + phase_s]
+            t0 = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(i, stop)) for i in range(T)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            dt = time.perf_counter() - t0
+        assert not err, f"svthip_motion_estimate_picture failed: 0x{err[0] & 0xffffffff:08x}"
+        out[f"threads_{T}"] = {"pictures_per_s": round(sum(done) / dt, 1), "ms_per_picture_per_thread": round(dt / max(1, max(done)) * 1e3, 3)}
+        for c in ctxs:
+            c.close()
+    up, down = 2 * W * H, n_sb * 85 * 40
+    out["pcie_bytes_per_picture"] = {"host_to_device": up, "device_to_host": down}
+    out["workload"] = ("svthip_motion_estimate_picture: one 1080p P picture per call (85 PUs, sub-pel on), host pointers, pageable memory, one context and "
+                       "one stream per host thread; compare legs.me_chain_subpel.85pu_P_subpel (12 pictures per call, device resident)")
+    return out
+
+
+def leg_batcher(ctx, torch, svtav1_hip, dev, rng):
+    """The batching layer where it will be used: the tx-type search of mode decision adds every (TU, tx_type) candidate of a
+    superblock's partition tree -- 64x64 (DCT), 4 x 32x32 (DCT, IDTX), 16 x 16x16, 64 x 8x8 and 256 x 4x4 with three types each: 1 017
+    candidates per SB -- and flushes once per G superblocks.  One flush = one descriptor upload, one fused launch per size present,
+    one download; G = 1 (what a serial SB loop gives), 8, 30 (an SB row of 1080p), 510 (a frame).  Adds are host-side appends in C and are
+    not timed (the Python ctypes loop that drives them here would dominate)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "quant_tables.npz"))
+    qrows = np.ascontiguousarray(z["rows_bd8_inter"][[20, 120, 200], 0, :])
+    d_qp = torch.from_numpy(qrows).to(dev)
+    d_iscan = torch.from_numpy(z["iscan_pool"]).to(dev)
+    pic_w, pic_h = 1920, 1088
+    src = torch.randint(0, 256, (pic_w * pic_h,), dtype=torch.uint8, device=dev)
+    pred = (src.short() + torch.randint(-6, 7, src.shape, dtype=torch.int16, device=dev)).clamp_(0, 255).to(torch.uint8)
+    per_sb = []   # (tx_size index, tx_type, x, y) of one superblock's candidates
+    for n, types in ((64, (0,)), (32, (0, 9)), (16, (0, 3, 9)), (8, (0, 3, 9)), (4, (0, 3, 9))):
+        ts = svtav1_hip.TX_SIZES_WH.index((n, n))
+        for y in range(0, 64, n):
+            for x in range(0, 64, n):
+                for t in types:
+                    per_sb.append((ts, t, x, y, int(z["scan_offsets"][int(z["scan_index"][ts, t])])))
+    cand_per_sb = len(per_sb)
+    coeff_per_sb = sum(min(svtav1_hip.TX_SIZES_WH[c[0]][0], 32) ** 2 for c in per_sb)
+    out = {"candidates_per_superblock": cand_per_sb}
+    SCR = 0xffffffff
+    for G in (1, 8, 30, 510):
+        b = svtav1_hip.TuBatcher(ctx, G * cand_per_sb, G * coeff_per_sb)
+        reps = 1 if G >= 510 else 3 if G >= 30 else 6
+        t_flush = 0.0
+        for _ in range(reps + 1):
+            b.begin(src.data_ptr(), pred.data_ptr(), None, 0, d_qp.data_ptr(), d_iscan.data_ptr())
+            for g in range(G):
+                ox, oy = (g % 30) * 64, (g // 30) * 64
+                for ts, t, x, y, isc in per_sb:
+                    off = (oy + y) * pic_w + ox + x
+                    b.add(ts, t, off, pic_w, off, pic_w, SCR, 0, g % 3, isc)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            b.flush()
+            dt = time.perf_counter() - t0
+            if _:
+                t_flush += dt
+        ms = t_flush / reps * 1e3
+        px = G * sum(svtav1_hip.TX_SIZES_WH[c[0]][0] ** 2 for c in per_sb)
+        out[f"flush_per_{G}_sb"] = {"ms_per_flush": round(ms, 4), "candidates_per_s": round(G * cand_per_sb / ms * 1e3, 0), "gpix_per_s": round(px / ms / 1e6, 3),
+                                    "ms_per_superblock": round(ms / G, 4)}
+        b.close()
+    out["workload"] = ("svthip_tu_batcher: 1 017 (TU, tx_type) candidates per superblock (1 x 64x64, 8 x 32x32, 48 x 16x16, 192 x 8x8, 768 x 4x4), real "
+                       "quantiser rows and scans, reconstruction into batcher scratch; wall time of flush = upload + five fused launches + download")
     return out
 
 
@@ -574,8 +916,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only")
     ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gather-results", action="store_true", help="also gather the (sad, mv) results of every step on every rank (svthip_me_gather_results_dev, RCCL)")
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        sys.exit(cpu_baseline_worker_main())
 
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
@@ -586,6 +931,12 @@ def main():
         if world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with --nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
+
+    cpu_worker = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU baselines run in a child started NOW, before this process touches a GPU; it idles until the GPU numbers are in
+        cpu_worker = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, text=True)
 
     import torch
     import torch.distributed as dist
@@ -679,13 +1030,18 @@ def main():
             legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
             legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
             legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)
+            legs["tu_batcher"] = leg_batcher(ctx, torch, svtav1_hip, dev, rng)
+            legs["host_pointer_threads"] = leg_host_threads(svtav1_hip)
 
     if rank == 0:
         value = total_blocks_per_step * args.steps / elapsed
         achieved = ALGO_BYTES_PER_BLOCK * n_blocks / (kern_ms * 1e-3) / 1e9
         absdiff_rate = ABSDIFF_PER_BLOCK * n_blocks / (kern_ms * 1e-3)
-        tr = load_profile_json("r02_pmc_traffic.json") or load_profile_json("r01_pmc_traffic.json") or {}
-        traffic = pmc_traffic_bytes(tr.get("svthip::fullpel85_kernel"))
+        rec85 = pmc_entry("fullpel85_kernel")
+        traffic = pmc_traffic_bytes(rec85)
+        if traffic is None:   # no round-3 profile in the tree: the round-2 record of the same launch
+            tr = load_profile_json("r02_pmc_traffic.json") or {}
+            traffic = pmc_traffic_bytes(tr.get("svthip::fullpel85_kernel"))
         out = {
             "metric": "64x64 SAD-search blocks/sec",
             "value": round(value, 1),
@@ -713,6 +1069,7 @@ def main():
                          "traffic_note": "bytes per launch of 6120 blocks = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 from separate rocprofv3 --pmc "
                                          "passes (profiles/*_pmc_traffic.json; FETCH_SIZE doubled as the MI355X guide prescribes for gfx950); "
                                          "algorithmic bytes per launch = 20905 x blocks",
+                         "valu_busy": counters(rec85, kern_ms, 0)["valu_busy"],
                          "kernel": "fullpel85_kernel", "kernel_ms": round(kern_ms, 4), "kernel_blocks": n_blocks,
                          "algorithmic_bytes_per_block": ALGO_BYTES_PER_BLOCK,
                          "note": "search is ~400 abs-diff per compulsory byte: VALU-bound by construction (SURVEY 8d); see valu",
@@ -722,12 +1079,25 @@ def main():
                                   "peak_source": "measured v_qsad_pk_u16_u8 issue rate, tools/ubench_valu.hip"}},
             "legs": legs,
         }
-        if not args.no_cpu_baseline and world == 1:
-            host_pool = pool[: pdesc[2].full_offset].cpu().numpy()            # pictures 0 and 1
-            desc0 = zero_centred_desc([pdesc[1]], [pdesc[0]], sb_all, W, H)
-            out["cpu_baseline"] = cpu_baseline(host_pool, stride, desc0)
+        if cpu_worker is not None:
+            try:
+                res, _ = cpu_worker.communicate("go\n", timeout=300)
+                cpu = json.loads(res.strip().splitlines()[-1])
+            except Exception as e:
+                cpu_worker.kill()
+                cpu = {"headline": {"error": f"{type(e).__name__}: {e}"}}
+            out["cpu_baseline"] = cpu.get("headline")
             if not args.no_legs:
-                legs.setdefault("sad_loop_480p", {})["cpu_baseline"] = cpu_sad_loop_baseline()
+                if cpu.get("sad_loop_480p"):
+                    legs.setdefault("sad_loop_480p", {})["cpu_baseline"] = cpu["sad_loop_480p"]
+                if cpu.get("me_chain_subpel.85pu_B_fullpel_only"):
+                    legs.setdefault("me_chain_subpel", {}).setdefault("85pu_B_fullpel_only", {})["cpu_baseline"] = cpu["me_chain_subpel.85pu_B_fullpel_only"]
+                if cpu.get("convolve_8tap"):
+                    legs.setdefault("convolve_8tap", {})["cpu_baseline"] = cpu["convolve_8tap"]
+                tq = cpu.get("tq_chain") or {}
+                for size, v in tq.items():
+                    if size in legs.get("tq_chain", {}).get("sizes", {}):
+                        legs["tq_chain"]["sizes"][size]["frame_1080p"]["cpu_baseline"] = v
         print(json.dumps(out), flush=True)
     ctx.close()
     if distributed:

@@ -134,3 +134,12 @@ printf '{ global: Av1TransformTwoD_*_c; av1_fwd_txfm2d_*_c; Av1InverseTransformT
 gcc -shared -o "$OUT/libsvtref_tq.so" "$OUT"/obj_all/*.o \
     -Wl,--gc-sections -Wl,--version-script="$OUT/obj/tq.map" -lm -lpthread
 echo "built $OUT/libsvtref_tq.so (unresolved: $(nm -D "$OUT/libsvtref_tq.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"
+
+# ---------------------------------------------------------------------------------------------
+# libsvtref_bench.so : batch loops over the reference's C transform / quantisation chain and single-reference convolutions for
+# bench.py's per-leg cpu_baseline (oracle/ref_bench_driver.c: calls only, no reference code).  Same objects, same no-stand-in rule.
+gcc -O2 -std=gnu99 -w -mavx2 -fPIC -ffunction-sections $INC -c "$HERE/ref_bench_driver.c" -o "$OUT/obj/ref_bench_driver.o"
+printf '{ global: ref_bench_tq_chain; ref_bench_convolve; local: *; };\n' > "$OUT/obj/bench.map"
+gcc -shared -o "$OUT/libsvtref_bench.so" "$OUT"/obj_all/*.o "$OUT/obj/ref_bench_driver.o" "$OUT/obj/ref_convolve_driver.o" \
+    -Wl,--gc-sections -Wl,--version-script="$OUT/obj/bench.map" -lm -lpthread
+echo "built $OUT/libsvtref_bench.so (unresolved: $(nm -D "$OUT/libsvtref_bench.so" | awk '$1=="U" && $2 !~ /@/ {printf "%s ", $2}'))"
