@@ -347,7 +347,7 @@ def pmc_traffic_bytes(entry):
 _PMC = None
 
 
-def pmc_entry(kernel, which=-1, workgroup=None):
+def pmc_entry(kernel, which=-1, workgroup=None, grid=None):
     """Counter record of one kernel from profiles/r03_pmc_traffic.json (tools/run_r03_pmc_traffic.sh: separate rocprofv3 --pmc passes over
     this very bench command).  Records of a kernel are sorted by grid size: which = -1 takes the largest launch, 0 the smallest;
     `workgroup` filters on the workgroup size.  None when the profile has no such kernel."""
@@ -361,6 +361,8 @@ def pmc_entry(kernel, which=-1, workgroup=None):
         return None
     if workgroup is not None:
         recs = [r for r in recs if r.get("workgroup") == workgroup]
+    if grid is not None:   # the launch with exactly this many threads
+        recs = [r for r in recs if r.get("grid") == grid]
     return recs[which] if recs else None
 
 
@@ -536,8 +538,10 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
             ms = timer.ms(run, 20 if label == "frame_1080p" else 5)
             px = n_tu * n * n
             algo = px * 3 + n_tu * nc * 6 + n_tu * 2
-            # rocprofv3 names the instantiation "encode_tu_kernel<N, N, unsigned char>"; its two launches differ in grid size
-            rec = pmc_entry(f"encode_tu_kernel<{n}, {n}, unsigned char", 0 if label == "frame_1080p" else -1)
+            # rocprofv3 names the instantiation by log2 of the sides, "encode_tu_kernel<4, 4, unsigned char>" = 16x16; other legs launch
+            # the same kernel with other grids: a wave owns 64 / n TUs, four waves per workgroup -> n_tu * n threads, whole workgroups
+            lg = n.bit_length() - 1
+            rec = pmc_entry(f"encode_tu_kernel<{lg}, {lg}, unsigned char", grid=(n_tu * n + 255) // 256 * 256)
             res[label] = {"n_tu": n_tu, "ms": round(ms, 4), "gpix_per_s": round(px / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
                           "frac_hbm_algorithmic": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4), **counters(rec, ms, algo)}
             del src, pred, recon, noise, d_q
@@ -917,6 +921,8 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="headline only")
     ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-host-threads", action="store_true", help="skip the multi-threaded host-pointer leg (counter collection under rocprofv3 "
+                                                                    "crashed inside the profiler when 20 host threads issued copies)")
     ap.add_argument("--gather-results", action="store_true", help="also gather the (sad, mv) results of every step on every rank (svthip_me_gather_results_dev, RCCL)")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -1031,7 +1037,8 @@ def main():
             legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
             legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)
             legs["tu_batcher"] = leg_batcher(ctx, torch, svtav1_hip, dev, rng)
-            legs["host_pointer_threads"] = leg_host_threads(svtav1_hip)
+            if not args.no_host_threads:
+                legs["host_pointer_threads"] = leg_host_threads(svtav1_hip)
 
     if rank == 0:
         value = total_blocks_per_step * args.steps / elapsed
