@@ -419,6 +419,10 @@ def tile_tu_desc(svtav1_hip, w, h, pic_w, pic_h, iscan_offset_by_type, tx_types,
     d["iscan_offset"] = np.asarray([iscan_offset_by_type[int(t)] for t in tt])
     d["src_stride"] = d["pred_stride"] = d["recon_stride"] = pic_w
     d["qparam_index"] = rng.integers(0, n_qrows, n_tu)
+    # descriptors ordered by transform type, as svthip_tu_batcher_flush emits them: a wave owns 64 / n consecutive TUs and its lanes
+    # branch on their TU's transform kinds, so mixed waves would run the DCT and the ADST network in every pass (TUs are independent)
+    if min(w, h) >= 8:
+        d = d[np.argsort(d["tx_type"], kind="stable")]
     return d, n
 
 
@@ -514,7 +518,8 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
     d_qp = torch.from_numpy(qrows).to(dev)
     d_iscan = torch.from_numpy(z["iscan_pool"]).to(dev)
     out = {"workload": "fused per-TU encode chain, 8-bit; quantiser rows = av1_build_quantizer luma rows at qindex 20/120/200; "
-                       "bytes/pixel algorithmic = 1 src + 1 pred + 1 recon + 4 qcoeff + 2 iscan = 9",
+                       "bytes/pixel algorithmic = 1 src + 1 pred + 1 recon + 4 qcoeff + 2 iscan = 9; descriptors ordered by transform type like the "
+                       "batcher's flush (a random order costs sizes <= 16x16 about a third more: mixed waves run both networks)",
            "sizes": {}}
     for n in (4, 8, 16, 32, 64):
         ts = svtav1_hip.TX_SIZES_WH.index((n, n))
@@ -921,6 +926,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="headline only")
     ap.add_argument("--no-hme", action="store_true", help="time the full-pel search alone (zero-centred windows)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--only-legs", default="", help="comma-separated leg names to run (development aid; default: all)")
     ap.add_argument("--no-host-threads", action="store_true", help="skip the multi-threaded host-pointer leg (counter collection under rocprofv3 "
                                                                     "crashed inside the profiler when 20 host threads issued copies)")
     ap.add_argument("--gather-results", action="store_true", help="also gather the (sad, mv) results of every step on every rank (svthip_me_gather_results_dev, RCCL)")
@@ -1024,20 +1030,30 @@ def main():
 
     legs = {}
     if not args.no_legs:
-        legs["recon_exchange"] = leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world)   # every rank takes part
+        want = set(filter(None, args.only_legs.split(",")))
+        on = lambda name: not want or name in want  # noqa: E731
+        if on("recon_exchange"):
+            legs["recon_exchange"] = leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world)   # every rank takes part
         if rank == 0:
             timer = EventTimer(torch)
             rng = np.random.default_rng(3)
             d_sb_all = torch.from_numpy(sb_all.view(np.int16).copy()).to(dev)
             params_b = svtav1_hip.default_me_params(W, H, 3, 1)
-            legs["me_chain_subpel"] = leg_me_chain(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
-            legs["open_loop_intra_search"] = leg_ois(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
-            legs["sad_loop_480p"] = leg_sad_loop(ctx, torch, svtav1_hip, timer, dev)
-            legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
-            legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
-            legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)
-            legs["tu_batcher"] = leg_batcher(ctx, torch, svtav1_hip, dev, rng)
-            if not args.no_host_threads:
+            if on("me_chain_subpel"):
+                legs["me_chain_subpel"] = leg_me_chain(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
+            if on("open_loop_intra_search"):
+                legs["open_loop_intra_search"] = leg_ois(ctx, torch, svtav1_hip, timer, pool, pdesc, params_b, d_sb_all, sb_all.shape[0], dev)
+            if on("sad_loop_480p"):
+                legs["sad_loop_480p"] = leg_sad_loop(ctx, torch, svtav1_hip, timer, dev)
+            if on("convolve_8tap"):
+                legs["convolve_8tap"] = leg_convolve(ctx, torch, svtav1_hip, timer, pool, pdesc, dev)
+            if on("tq_chain"):
+                legs["tq_chain"] = leg_tq(ctx, torch, svtav1_hip, timer, dev, rng)
+            if on("uhd_10bit"):
+                legs["uhd_10bit"] = leg_4k(ctx, torch, svtav1_hip, timer, dev, rng)
+            if on("tu_batcher"):
+                legs["tu_batcher"] = leg_batcher(ctx, torch, svtav1_hip, dev, rng)
+            if on("host_pointer_threads") and not args.no_host_threads:
                 legs["host_pointer_threads"] = leg_host_threads(svtav1_hip)
 
     if rank == 0:

@@ -99,6 +99,12 @@ __global__ void __launch_bounds__(256) sad_loop_kernel(const uint8_t* __restrict
     }
 }
 
+__host__ __device__ inline int sad_loop_qsad_pitch(int w, int sw)
+{
+    const int p = (8 * ((sw + 7) >> 3) + w + 4 + 7) & ~7;
+    return (p & 8) ? p : p + 8;
+}
+
 // Fast path for block widths 4 / 8 / 16 / 32 / 64 (W4 = width / 4 dwords): same slice layout and staging, but a lane owns EIGHT
 // consecutive positions of one search row and the window dwords of a block row live in registers: per source dword two
 // v_qsad_pk_u16_u8 (positions 0..3 on the dword pair (j, j + 1), 4..7 on (j + 1, j + 2)) -- 16 abs-diff per instruction instead of 4.
@@ -116,11 +122,13 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
     const uint32_t b = blockIdx.x * 4 + wave;
     if (b >= n_blocks) return;  // whole wave; no workgroup barrier below
     lds_u8* blk = (lds_u8*)smem + wave * slice_bytes;
-    lds_u8* win = blk + h * w;
+    lds_u8* win = blk + ((h * w + 7) & ~7);  // 8-byte aligned for the paired reads
     const int k = (int)(ref_stride / ref_stride_raw);
     const int ng = (sw + 7) >> 3;                                      // 8-position groups per search row
     const int wrows = (sh - 1) + (h - 1) * k + 1, wcols = w + sw - 1;
-    const int pitch = (8 * ng + w + 4 + 3) & ~3;                       // every group's W4 + 2 dwords exist (zero beyond the window)
+    // every group's W4 + 2 dwords (+ 1: they are read as 8-byte pairs) exist (zero beyond the window); rows are an ODD number of 8-byte
+    // units so that the ds_read_b64 of lanes on neighbouring search rows fall on different banks
+    const int pitch = sad_loop_qsad_pitch(w, sw);
     const svthip_sad_loop_desc d = desc[b];
 #pragma unroll 2
     for (int i = lane; i < h * W4; i += 64) {
@@ -133,9 +141,11 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
     {
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(ref + d.ref_offset);
         const int ndw = pitch >> 2;
+        const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;  // i / ndw for i < 2^14 (a slice is at most 16 KB): the emulated division was
+                                                               // ~20 of the ~35 vector instructions of a staging pass (round 3)
 #pragma unroll 4
         for (int i = lane; i < wrows * ndw; i += 64) {
-            const int r = i / ndw, c = i - r * ndw;
+            const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
             const uintptr_t a = a0 + (size_t)r * ref_stride_raw + 4 * c;
             const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
             reinterpret_cast<lds_u32*>(win)[i] = 4 * c < wcols + 3 ? __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u)) : 0u;
@@ -146,8 +156,9 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
 
     uint32_t best = 0xffffffffu;
     const int n_items = ng * sh;
+    const uint32_t inv_ng = (1u << 20) / (uint32_t)ng + 1u;  // it / ng for it < 4096 * 8
     for (int it = lane; it < n_items; it += 64) {
-        const int ys = it / ng, x0 = 8 * (it - ys * ng);
+        const int ys = (int)(((uint32_t)it * inv_ng) >> 20), x0 = 8 * (it - ys * ng);
         uint32_t sum[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) sum[i] = 0;
@@ -159,9 +170,15 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
             for (int y = y0; y < y1; y++) {
                 const lds_u32* srow = reinterpret_cast<const lds_u32*>(blk) + y * W4;
                 const lds_u32* rrow = wp + y * rstep;
-                uint32_t W[W4 + 2];
+                uint32_t W[W4 + 3];
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
 #pragma unroll
-                for (int j = 0; j < W4 + 2; j++) W[j] = rrow[j];
+                for (int j = 0; j < (W4 + 3) / 2; j++) {  // 8-byte aligned: x0 is a multiple of 8 and so is the pitch
+                    const u32x2 t = reinterpret_cast<const lds_u32x2*>(rrow)[j];
+                    W[2 * j] = t.x;
+                    W[2 * j + 1] = t.y;
+                }
 #pragma unroll
                 for (int j = 0; j < W4; j++) {
                     const uint32_t sj = srow[j];
@@ -200,8 +217,8 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
 
 size_t sad_loop_qsad_slice_bytes(int w, int h, int sw, int sh, int k)
 {
-    const int wrows = (sh - 1) + (h - 1) * k + 1, pitch = (8 * ((sw + 7) >> 3) + w + 4 + 3) & ~3;
-    return ((size_t)h * w + (size_t)wrows * pitch + 8 + 15) & ~(size_t)15;
+    const int wrows = (sh - 1) + (h - 1) * k + 1, pitch = sad_loop_qsad_pitch(w, sw);
+    return ((((size_t)h * w + 7) & ~(size_t)7) + (size_t)wrows * pitch + 8 + 15) & ~(size_t)15;
 }
 
 hipError_t launch_sad_loop_qsad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t ref_stride_raw,

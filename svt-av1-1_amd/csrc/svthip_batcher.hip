@@ -36,8 +36,14 @@ struct svthip_tu_batcher {
     bool bound;
     // candidates since begin
     std::vector<Cand> cands;
-    std::vector<svthip_tu_desc> group[19];
-    std::vector<uint32_t> group_handle[19];
+    // candidates bucketed as they are added: [transform size][reconstruct into scratch?][transform type] -- a flush only concatenates.
+    // Ordering a launch by transform type matters: a wave of the fused kernel owns 64 / min(W, H) consecutive TUs and its lanes branch on
+    // their TU's 1-D transform kinds, so a wave of mixed types executes the DCT AND the ADST network in every one of its four passes;
+    // sorted, almost every wave runs one network (TUs are independent: the order changes nothing but the time).  4-point dimensions stay
+    // in the caller's order (bucket 0): their networks are a handful of instructions and neighbouring TUs share cache lines.
+    std::vector<svthip_tu_desc> group[19][2][16];
+    std::vector<uint32_t> group_handle[19][2][16];
+    uint32_t group_count[19];  // candidates of a size (slot numbering)
     size_t coeff_used, recon_used;
     size_t flushed;  // candidates already launched
     // device pools
@@ -126,8 +132,12 @@ int32_t svthip_tu_batcher_begin(svthip_tu_batcher* b, const void* d_src, const v
     b->cands.clear();
     b->results.clear();
     for (int i = 0; i < 19; i++) {
-        b->group[i].clear();
-        b->group_handle[i].clear();
+        b->group_count[i] = 0;
+        for (int sc = 0; sc < 2; sc++)
+            for (int t = 0; t < 16; t++) {
+                b->group[i][sc][t].clear();
+                b->group_handle[i][sc][t].clear();
+            }
     }
     b->coeff_used = b->recon_used = b->flushed = 0;
     return SVTHIP_OK;
@@ -144,6 +154,7 @@ int32_t svthip_tu_batcher_add(svthip_tu_batcher* b, uint32_t tx_size, uint32_t t
     if (b->coeff_used + n > b->max_coeff) return SVTHIP_ERR_INSUFFICIENT_RESOURCES;
     if (src_stride > 0xffff || pred_stride > 0xffff || qparam_index > 0xffff || (iscan_offset & 3u)) return SVTHIP_ERR_BAD_PARAMETER;
     svthip_tu_desc d;
+    int scratch = 0;
     memset(&d, 0, sizeof(d));
     d.src_offset = src_offset;
     d.pred_offset = pred_offset;
@@ -154,7 +165,7 @@ int32_t svthip_tu_batcher_add(svthip_tu_batcher* b, uint32_t tx_size, uint32_t t
         // the flush marks scratch tiles with the top bit of recon_stride's companion: a scratch tile has stride = width
         d.recon_offset = (uint32_t)b->recon_used;
         d.recon_stride = (uint16_t)w;
-        d.reserved[0] = 1;  // host-side tag, cleared before upload: reconstruct into the scratch pool
+        scratch = 1;  // reconstruct into the scratch pool (a launch has ONE reconstruction plane)
         b->recon_used += (size_t)w * h;
     } else {
         if (!b->d_recon || recon_stride > 0xffff) return SVTHIP_ERR_BAD_PARAMETER;
@@ -165,10 +176,11 @@ int32_t svthip_tu_batcher_add(svthip_tu_batcher* b, uint32_t tx_size, uint32_t t
     d.iscan_offset = iscan_offset;
     d.qparam_index = (uint16_t)qparam_index;
     d.tx_type = (uint8_t)tx_type;
-    Cand c = {(uint8_t)tx_size, (uint8_t)tx_type, (uint32_t)b->group[tx_size].size(), d.coeff_offset};
+    Cand c = {(uint8_t)tx_size, (uint8_t)tx_type, b->group_count[tx_size]++, d.coeff_offset};
     *out_handle = (uint32_t)b->cands.size();
-    b->group_handle[tx_size].push_back(*out_handle);
-    b->group[tx_size].push_back(d);
+    const int bucket = (w >= 8 && h >= 8) ? (int)tx_type : 0;
+    b->group_handle[tx_size][scratch][bucket].push_back(*out_handle);
+    b->group[tx_size][scratch][bucket].push_back(d);
     b->cands.push_back(c);
     b->coeff_used += n;
     return SVTHIP_OK;
@@ -192,13 +204,13 @@ int32_t svthip_tu_batcher_flush(svthip_tu_batcher* b)
     for (int ts = 0; ts < 19; ts++)
         for (int scratch = 0; scratch < 2; scratch++) {
             const uint32_t first = base;
-            for (size_t i = 0; i < b->group[ts].size(); i++)
-                if ((int)b->group[ts][i].reserved[0] == scratch) {
-                    svthip_tu_desc d = b->group[ts][i];
-                    d.reserved[0] = 0;  // host-side tag
-                    b->h_desc[base++] = d;
-                    b->launch_handle.push_back(b->group_handle[ts][i]);
-                }
+            for (int t = 0; t < 16; t++) {
+                const std::vector<svthip_tu_desc>& g = b->group[ts][scratch][t];
+                if (g.empty()) continue;
+                memcpy(b->h_desc + base, g.data(), sizeof(svthip_tu_desc) * g.size());
+                b->launch_handle.insert(b->launch_handle.end(), b->group_handle[ts][scratch][t].begin(), b->group_handle[ts][scratch][t].end());
+                base += (uint32_t)g.size();
+            }
             if (base != first) launches[n_launch++] = Launch{ts, scratch, first, base - first};
         }
     const size_t total = base;

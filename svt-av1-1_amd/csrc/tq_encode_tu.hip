@@ -53,8 +53,13 @@ __device__ __forceinline__ int group_max_i32(int v)
 
 // PIX = uint8_t: 8-bit planes (bd 8, quantize_b_helper_c_II); PIX = uint16_t: 10-bit samples in 16-bit planes (bd 10,
 // highbd_quantize_b_helper_c, Av1InvTransformRecon)
-template <int WL, int HL, typename PIX>
-__global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ src, const PIX* pred,
+// DIST: the coefficient-domain distortion sums of mode decision's full loop are wanted (dist_out != NULL).  The encode pass does not ask
+// for them, and they cost three vector instructions per coefficient plus two 64-bit reductions per TU in a kernel that is bound by
+// vector-instruction issue: a template parameter, not a run-time test inside the coefficient loop.
+// 64-point sizes: their LDS tiles allow two waves per SIMD anyway, so the register allocator gets all 256 (left at its default it squeezed the
+// variant without distortion sums into 165 VGPRs and that code ran 40 % slower than the 213-VGPR one).
+template <int WL, int HL, typename PIX, bool DIST>
+__global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_kernel(const PIX* __restrict__ src, const PIX* pred,
                                                         PIX* recon, const svthip_tu_desc* __restrict__ desc, uint32_t n_tu,
                                                         const int16_t* __restrict__ qparams, const int16_t* __restrict__ iscan_pool,
                                                         int32_t* __restrict__ coeff_out, int32_t* __restrict__ qcoeff_out,
@@ -152,7 +157,8 @@ __global__ void __launch_bounds__(256) encode_tu_kernel(const PIX* __restrict__ 
                             if (qv[k] != 0) last = max(last, isv[k] + 1);
                             // coefficients and their reconstructions are far below 2^30 here (transform of 8/10-bit
                             // residuals), so the difference is exact in 32 bits and each square is one v_mad_i64_i32
-if constexpr (H > 32) {
+                            if constexpr (!DIST) {
+                            } else if constexpr (H > 32) {
                                 // measured: with 64 rows per TU the plain C++ form is faster than the explicit mads
                                 // (0.245 vs 0.36 ms per 16384 64x64 TUs), for every other height it is the other way round
                                 const int64_t d64 = (int64_t)y[c + k] - dq[c + k];
@@ -189,13 +195,15 @@ if constexpr (H > 32) {
             }
             // per-TU reductions across the H lanes of the TU (inactive lanes contribute zeros)
             last = group_max_i32<H>(last);
-            dist_res = (int64_t)group_sum_u64<H>((uint64_t)dist_res);
-            dist_pred = (int64_t)group_sum_u64<H>((uint64_t)dist_pred);
+            if constexpr (DIST) {
+                dist_res = (int64_t)group_sum_u64<H>((uint64_t)dist_res);
+                dist_pred = (int64_t)group_sum_u64<H>((uint64_t)dist_pred);
+            }
             if constexpr (W > 32 || H > 32) energy = (int64_t)group_sum_u64<H>((uint64_t)energy);
             if (active && r == 0) {
                 eob_out[tu] = (uint16_t)last;
                 if (energy_out) energy_out[tu] = (uint64_t)energy;
-                if (dist_out) {
+                if constexpr (DIST) {
                     dist_out[2 * (size_t)tu] = (uint64_t)dist_res;
                     dist_out[2 * (size_t)tu + 1] = (uint64_t)dist_pred;
                 }
@@ -249,12 +257,19 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
     uint32_t blocks = (groups + 3) / 4;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
     if (lds > 64 * 1024) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return attr;
+        static hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr0 != hipSuccess) return attr0;
+        if (attr1 != hipSuccess) return attr1;
     }
-    hipLaunchKernelGGL((encode_tu_kernel<WL, HL, PIX>), dim3(blocks), dim3(256), lds, s, src, pred, recon, desc, n_tu, qparams, iscan, coeff,
-                       qcoeff, dqcoeff, eob, energy, dist);
+    if (dist)
+        hipLaunchKernelGGL((encode_tu_kernel<WL, HL, PIX, true>), dim3(blocks), dim3(256), lds, s, src, pred, recon, desc, n_tu, qparams, iscan,
+                           coeff, qcoeff, dqcoeff, eob, energy, dist);
+    else
+        hipLaunchKernelGGL((encode_tu_kernel<WL, HL, PIX, false>), dim3(blocks), dim3(256), lds, s, src, pred, recon, desc, n_tu, qparams, iscan,
+                           coeff, qcoeff, dqcoeff, eob, energy, dist);
     return hipGetLastError();
 }
 
