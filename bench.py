@@ -966,7 +966,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     ctx = svtav1_hip.Context(local_rank)
-    comm = sharded.Comm.from_process_group(ctx)      # svthip_comm (RCCL); world 1 never touches RCCL
+    try:
+        comm = sharded.Comm.from_process_group(ctx)  # svthip_comm (RCCL); world 1 never touches RCCL
+        comm_error = None
+    except Exception as e:   # the headline needs no exchange: report it, and the exchange leg's failure, rather than nothing
+        comm, comm_error = None, f"{type(e).__name__}: {e}"
+        print(f"bench.py: rank {rank}: svthip_comm_create failed: {comm_error}", file=sys.stderr)
 
     # ---- headline: frame-sharded hierarchical ME ----
     n_jobs = PICTURES_PER_STEP * world
@@ -998,7 +1003,7 @@ def main():
         if not args.no_hme:
             ctx.hme_search_center_batch_dev(pool.data_ptr(), curs, refs, params, 0, d_sb.data_ptr(), n_local, None, d_desc.data_ptr())
         ctx.fullpel_search_dev(*a)
-        if args.gather_results:   # svthip_me_gather_results_dev on the same stream: every rank ends with all (SAD, MV) rows
+        if args.gather_results and comm is not None:   # svthip_me_gather_results_dev on the same stream: every rank ends with all (SAD, MV) rows
             comm.me_gather_results_dev(d_sad.data_ptr(), g_sad.data_ptr(), n_jobs, n_total, 85 * 4)
             comm.me_gather_results_dev(d_mv.data_ptr(), g_mv.data_ptr(), n_jobs, n_total, 85 * 4)
 
@@ -1033,7 +1038,14 @@ def main():
         want = set(filter(None, args.only_legs.split(",")))
         on = lambda name: not want or name in want  # noqa: E731
         if on("recon_exchange"):
-            legs["recon_exchange"] = leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world)   # every rank takes part
+            # every rank takes part; all ranks agree on whether the communicator exists before entering the collective leg
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=dev)
+            if distributed:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
+                legs["recon_exchange"] = leg_recon_exchange(ctx, comm, torch, dist, svtav1_hip, dev, world)
+            else:
+                legs["recon_exchange"] = {"error": comm_error or "svthip_comm_create failed on another rank"}
         if rank == 0:
             timer = EventTimer(torch)
             rng = np.random.default_rng(3)
@@ -1122,6 +1134,8 @@ def main():
                     if size in legs.get("tq_chain", {}).get("sizes", {}):
                         legs["tq_chain"]["sizes"][size]["frame_1080p"]["cpu_baseline"] = v
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     ctx.close()
     if distributed:
         dist.barrier()

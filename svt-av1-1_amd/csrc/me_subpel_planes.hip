@@ -363,6 +363,18 @@ __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
 
 }  // namespace
 
+// Optional per-phase time stamps (tools/subpel_stamps_probe.py builds a variant with -DSVTHIP_SUBPEL_STAMPS): s_memtime of wave 0's
+// lane 0 at the phase boundaries, [superblock][8].
+#ifdef SVTHIP_SUBPEL_STAMPS
+__device__ unsigned long long g_subpel_stamps[8192 * 8];
+#define SUBPEL_STAMP(i)                                                                                          \
+    do {                                                                                                         \
+        if (tid == 0 && sb < 8192u) g_subpel_stamps[(size_t)sb * 8 + (i)] = __builtin_amdgcn_s_memtime();        \
+    } while (0)
+#else
+#define SUBPEL_STAMP(i) do { } while (0)
+#endif
+
 // One workgroup per (SB, list): 512 threads (8 wave tasks) for the 85 squares, 448 threads (7 waves x 4 tasks) for all 209 PUs.
 // io arrays [n_sb][n_pu] in ME-buffer order, refined in place; pred_out (optional) [n_sb][slots][1024 dwords].
 __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
@@ -394,6 +406,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     P.dBH = (P.PB * rows_a + 15) & ~15;
     P.dHJ = (P.PB * rows_h + 15) & ~15;
 
+    SUBPEL_STAMP(0);
     // ---- bounding box of the samples the PUs can touch: x in [bx - 1, bx + W + 1], y in [by - 1, by + H + 1] ----
     // Every wave computes it for itself (two independent coalesced loads per lane, a DPP / bpermute min-max over the wave): no LDS, no
     // workgroup barrier, one memory latency.  (First version: LDS atomics by the first n_pu threads between two barriers with a
@@ -423,11 +436,16 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     Y1 = __builtin_amdgcn_readfirstlane(min(Y1, sh + 64));
     // dword columns of the b / h / j planes to fill (plane column = x + 1) and rows.  Rows go to waves, dword columns to lanes (two rows
     // per wave pass when a row is at most 32 dwords): no integer division, coalesced row reads, loads of four rows in flight per lane.
+    SUBPEL_STAMP(1);
     const int c0 = (X0 + 1) >> 2, c1 = (X1 + 1) >> 2, ncol = c1 - c0 + 1;
     const int two = ncol + 1 <= 32 ? 1 : 0;                     // A rows are ncol + 1 dwords
     const int cc = c0 + (two ? (lane & 31) : lane), rsub = two ? (lane >> 5) : 0, rstep = n_waves << two;
     const int rfirst = (wave << two) + rsub;
+#ifdef SVTHIP_SUBPEL_EXPERIMENT_NO_PLANES  // timing experiments only (tools/build_variant.sh): results are wrong
+    if (false) {
+#else
     if (ncol > 0 && Y1 >= Y0) {
+#endif
         // ---- A: rows Y0 - 2 .. Y1 + 1, plane dword columns c0 .. c1 + 1 (plane column = x + 3: b's 4 samples at dword c read A dwords c, c + 1) ----
         {
             const uint8_t* base = ref_plane + ref_off - 3;  // plane column 0 = x = -3
@@ -452,6 +470,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
             }
         }
         __syncthreads();
+        SUBPEL_STAMP(2);
         // ---- b rows Y0 - 2 .. Y1 + 1 and h rows Y0 .. Y1 ----
         if (cc <= c1) {
             const int nrb = Y1 - Y0 + 4;
@@ -475,6 +494,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
             }
         }
         __syncthreads();
+        SUBPEL_STAMP(3);
         // ---- j rows Y0 .. Y1 from the ROUNDED b rows y - 2 .. y + 1 ----
         if (cc <= c1) {
             const int nrh = Y1 - Y0 + 1, pb4 = P.PB >> 2;
@@ -486,6 +506,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
         }
     }
     __syncthreads();
+    SUBPEL_STAMP(4);
 
     Ctx c;
     c.src = src_plane + src_off;
@@ -499,7 +520,11 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.shake = ctl + 4;
     c.lane = lane;
     c.method = __builtin_amdgcn_readfirstlane(method);
+#ifdef SVTHIP_SUBPEL_EXPERIMENT_NO_PU
+    const int n_tasks = 0;
+#else
     const int n_tasks = n_pu == 209 ? 28 : 8;
+#endif
 #pragma unroll 1
     for (int task = wave; task < n_tasks; task += n_waves) {
         const int cls = __builtin_amdgcn_readfirstlane(task >> 1), half = task & 1;
@@ -521,7 +546,15 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
         default: run_class<13>(c, half, refine); break;
         }
     }
+    SUBPEL_STAMP(5);
 }
+
+#ifdef SVTHIP_SUBPEL_STAMPS
+extern "C" int svthip_debug_subpel_stamps(void* host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_subpel_stamps), bytes < sizeof(g_subpel_stamps) ? bytes : sizeof(g_subpel_stamps));
+}
+#endif
 
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
