@@ -544,9 +544,10 @@ def leg_tq(ctx, torch, svtav1_hip, timer, dev, rng):
             px = n_tu * n * n
             algo = px * 3 + n_tu * nc * 6 + n_tu * 2
             # rocprofv3 names the instantiation by log2 of the sides, "encode_tu_kernel<4, 4, unsigned char>" = 16x16; other legs launch
-            # the same kernel with other grids: a wave owns 64 / n TUs, four waves per workgroup -> n_tu * n threads, whole workgroups
+            # the same kernel with other grids: a wave owns 64 / n TUs, four waves per workgroup -> n_tu * n threads in whole workgroups,
+            # capped at 256 x 64 workgroups (grid-stride beyond that); the trailing "false" = no distortion sums asked for
             lg = n.bit_length() - 1
-            rec = pmc_entry(f"encode_tu_kernel<{lg}, {lg}, unsigned char", grid=(n_tu * n + 255) // 256 * 256)
+            rec = pmc_entry(f"encode_tu_kernel<{lg}, {lg}, unsigned char, false>", grid=min((n_tu * n + 255) // 256, 256 * 64) * 256)
             res[label] = {"n_tu": n_tu, "ms": round(ms, 4), "gpix_per_s": round(px / ms / 1e6, 2), "algorithmic_gbps": round(algo / ms / 1e6, 1),
                           "frac_hbm_algorithmic": round(algo / ms / 1e6 / HBM_PEAK_GBPS, 4), **counters(rec, ms, algo)}
             del src, pred, recon, noise, d_q
