@@ -393,27 +393,8 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         const int nitems = nit * bh;
-        for (int it0 = 0; it0 < nitems; it0 += 64) {
-            const int item = min(it0 + lane, nitems - 1);
-            const bool valid = it0 + lane < nitems;
-            const int iy = (int)(((uint32_t)item * inv_nit) >> 20), io = item - iy * nit;
-            const uint32_t* w0 = win + iy * pitch + 4 * io;
-            uint64_t acc[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < H; r++) {
-                const uint32_t* wr = w0 + 2 * r * pitch;
-                const uint4 da = *reinterpret_cast<const uint4*>(wr);
-                const uint4 db = *reinterpret_cast<const uint4*>(wr + 4);
-                const uint4 sv = *reinterpret_cast<const uint4*>(srcbuf + r * WD);
-                const uint32_t d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
-                const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-                for (int c = 0; c < WD; c++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        acc[g] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(d[c + g], d[c + g + 1]), s4[c], acc[g]);
-            }
-            // 16 keys: (sad << 16) + raster index; positions beyond the search width and padding lanes never win
+        // 16 keys of one item: (sad << 16) + raster index; positions beyond the search width and lanes without an item never win
+        auto track = [&](const uint64_t* acc, int iy, int io, bool valid) {
             const int xs0 = 16 * io;
             const uint32_t base = (uint32_t)((y0 + iy) * sw + xs0);
             if ((sw & 15) == 0) {
@@ -427,7 +408,7 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
                     lb = min3u((hi << 16) | (ix + 2u), (hi & 0xffff0000u) | (ix + 3u), lb);
                 }
                 best = min(best, valid ? lb : 0xffffffffu);
-                continue;
+                return;
             }
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -440,6 +421,54 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
                     best = min(best, key);
                 }
             }
+        };
+        auto row_sads = [&](const uint32_t* wr, int r, uint64_t* acc) {
+            const uint4 da = *reinterpret_cast<const uint4*>(wr);
+            const uint4 db = *reinterpret_cast<const uint4*>(wr + 4);
+            const uint4 sv = *reinterpret_cast<const uint4*>(srcbuf + r * WD);
+            const uint32_t d[8] = {da.x, da.y, da.z, da.w, db.x, db.y, db.z, db.w};
+            const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+            for (int c = 0; c < WD; c++)
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    acc[g] = __builtin_amdgcn_qsad_pk_u16_u8(pack64(d[c + g], d[c + g + 1]), s4[c], acc[g]);
+        };
+        int it0 = 0;
+        // whole passes: a lane owns an item (all 8 block rows, 128 v_qsad)
+        for (; nitems - it0 >= 57; it0 += 64) {
+            const int item = min(it0 + lane, nitems - 1);
+            const bool valid = it0 + lane < nitems;
+            const int iy = (int)(((uint32_t)item * inv_nit) >> 20), io = item - iy * nit;
+            const uint32_t* w0 = win + iy * pitch + 4 * io;
+            uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < H; r++) row_sads(w0 + 2 * r * pitch, r, acc);
+            track(acc, iy, io, valid);
+        }
+        // the remainder: 2 / 4 / 8 lanes share an item and split its block rows, so that a handful of left-over items does not cost a
+        // whole 128-v_qsad pass with most lanes idle (the reference's 100 % level-0 area is 72 items: 64 + 8; the 200 % area 288 = 4 x 64 + 32).
+        // The 16-bit partial sums of an item's lanes are added as packed pairs (a 16 x 8 SAD is < 2^16).
+        while (it0 < nitems) {
+            const int rem = nitems - it0;
+            const int rp_shift = rem > 32 ? 1 : rem > 16 ? 1 : rem > 8 ? 2 : 3;
+            const int RP = 1 << rp_shift, take = min(rem, 64 >> rp_shift);
+            const int slot = lane >> rp_shift, part = lane & (RP - 1);
+            const int item = it0 + min(slot, take - 1);
+            const int iy = (int)(((uint32_t)item * inv_nit) >> 20), io = item - iy * nit;
+            const uint32_t* w0 = win + iy * pitch + 4 * io;
+            uint64_t acc[4] = {0, 0, 0, 0};
+            for (int r = part; r < H; r += RP) row_sads(w0 + 2 * r * pitch, r, acc);
+            for (int m = 1; m < RP; m <<= 1) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t lo = (uint32_t)acc[g] + (uint32_t)__shfl_xor((int)(uint32_t)acc[g], m);
+                    const uint32_t hi = (uint32_t)(acc[g] >> 32) + (uint32_t)__shfl_xor((int)(uint32_t)(acc[g] >> 32), m);
+                    acc[g] = pack64(lo, hi);
+                }
+            }
+            track(acc, iy, io, slot < take && part == 0);
+            it0 += take;
         }
         __builtin_amdgcn_wave_barrier();
     }

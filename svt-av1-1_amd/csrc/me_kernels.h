@@ -58,6 +58,7 @@ __global__ void subpel_planes_kernel(const uint8_t* __restrict__ src_plane, uint
                                      uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, int disable_8x8, int n_pu,
                                      uint32_t* __restrict__ io_sad, uint32_t* __restrict__ io_mv, uint32_t* __restrict__ pred_out, int method);
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh);
+uint32_t subpel_planes_grid(uint32_t n_sb);
 __global__ void bipred_stored_pack_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const int32_t* __restrict__ desc0,
                                           const uint8_t* __restrict__ pred0, const uint8_t* __restrict__ pred1,
                                           const uint32_t* __restrict__ sad0, const uint32_t* __restrict__ mv0,

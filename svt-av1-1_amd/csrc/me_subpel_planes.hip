@@ -118,7 +118,7 @@ __device__ __forceinline__ uint32_t plane_addr(const Planes& P, int p, int x, in
 // SADM: one of the SAD search methods (c.method 0 / 1) instead of SSD_SEARCH -- a template parameter so that the SSD instantiation, the
 // one MotionEstimateLcu uses, carries none of the other methods' code (as a run-time branch it cost 136 bytes of scratch and 3-5 %).
 template <int W, int H, int CLS, bool SADM>
-__device__ void refine_class_half(const Ctx& c, int half, bool refine)
+__device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_first, int u_count)
 {
     constexpr int CW = W / 8, CPP = CW * (H / 8);                 // cells per PU
     constexpr int UNITS = CPP >= 4 ? 1 : 4 / CPP;                  // PUs per chunk
@@ -128,8 +128,9 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
     constexpr bool TWO_WAVES = CPP > 32;                           // 64x64: the other half of the PU is on the partner wave
     const int g = c.lane >> 3, r = c.lane & 7, chunk = 8 * half + g;
     const int pa8 = 8 * c.P.PA, pb8 = 8 * c.P.PB;
+    // u_first / u_count: the slice of the chunk's UNITS PUs this task covers (classes with one PU per chunk: 0 / 1)
 #pragma unroll 1
-    for (int u = 0; u < UNITS; u++) {
+    for (int u = (UNITS > 1 ? u_first : 0); u < (UNITS > 1 ? u_first + u_count : 1); u++) {
         constexpr int CQ = CPP >= 4 ? CPP / 4 : 1;  // chunks per PU
         const int pu_in_class = CPP >= 4 ? chunk / CQ : chunk * UNITS + u;
         const int cell0 = CPP >= 4 ? (chunk % CQ) * 4 : 0;
@@ -355,11 +356,35 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine)
 }
 
 template <int CLS>
-__device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
+__device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine, int u_first, int u_count)
 {
-    if (c.method == 2) refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, false>(c, half, refine);
-    else refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, true>(c, half, refine);
+    if (c.method == 2) refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, false>(c, half, refine, u_first, u_count);
+    else refine_class_half<kClass[CLS].w, kClass[CLS].h, CLS, true>(c, half, refine, u_first, u_count);
 }
+
+// Which wave refines what.  A task = (class, half, slice of the chunk's PUs) = 8 chunks of 4 cells, i.e. the same pixels whatever the class --
+// but not the same time: a chunk of a class with small PUs runs the per-PU part (vector / table reads, 17 + 6 lane-group sums, decisions,
+// quarter-pel set-up) once per PU, and per-wave time stamps (tools/subpel_stamps_probe.py) showed the two 8x8 waves of the 85-PU mode at
+// 23.8 k ticks against 13 - 15 k for the other six, with the workgroup (and its 71 KB of LDS) waiting for them.  So the classes with 4 / 2
+// PUs per chunk (8x8; 16x8, 8x16) are cut into per-PU slices and dealt out by measured cost.  Entry: class | half << 4 | first << 5 |
+// count << 7, 0xffff ends a wave's list.  The two halves of the 64x64 PU (which hand-shake through the LDS) lead the lists of two waves.
+#define T(cls, half, first, count) (uint16_t)((cls) | ((half) << 4) | ((first) << 5) | ((count) << 7))
+#define TEND (uint16_t)0xffff
+__device__ constexpr uint16_t kTasks85[8][4] = {
+    {T(0, 0, 0, 1), TEND, TEND, TEND},          {T(0, 1, 0, 1), TEND, TEND, TEND},
+    {T(1, 0, 0, 1), T(3, 0, 0, 1), TEND, TEND}, {T(1, 1, 0, 1), T(3, 1, 0, 1), TEND, TEND},
+    {T(2, 0, 0, 1), TEND, TEND, TEND},          {T(2, 1, 0, 1), TEND, TEND, TEND},
+    {T(3, 0, 1, 3), TEND, TEND, TEND},          {T(3, 1, 1, 3), TEND, TEND, TEND}};
+__device__ constexpr uint16_t kTasks209[7][6] = {
+    {T(0, 0, 0, 1), T(3, 1, 0, 3), T(7, 0, 0, 1), T(10, 1, 0, 1), TEND, TEND},
+    {T(0, 1, 0, 1), T(4, 0, 0, 1), T(7, 1, 0, 1), T(11, 0, 0, 1), T(3, 1, 3, 1), TEND},
+    {T(1, 0, 0, 1), T(4, 1, 0, 1), T(8, 0, 0, 1), T(11, 1, 0, 1), T(3, 0, 2, 2), TEND},
+    {T(1, 1, 0, 1), T(5, 0, 0, 1), T(8, 1, 0, 1), T(12, 0, 0, 1), T(9, 0, 1, 1), TEND},
+    {T(2, 0, 0, 1), T(5, 1, 0, 1), T(9, 0, 0, 1), T(12, 1, 0, 1), TEND, TEND},
+    {T(2, 1, 0, 1), T(6, 0, 0, 2), T(9, 1, 0, 2), T(13, 0, 0, 1), TEND, TEND},
+    {T(3, 0, 0, 2), T(6, 1, 0, 2), T(10, 0, 0, 1), T(13, 1, 0, 1), TEND, TEND}};
+#undef T
+#undef TEND
 
 }  // namespace
 
@@ -367,6 +392,7 @@ __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine)
 // lane 0 at the phase boundaries, [superblock][8].
 #ifdef SVTHIP_SUBPEL_STAMPS
 __device__ unsigned long long g_subpel_stamps[8192 * 8];
+__device__ unsigned long long g_subpel_wave_end[8192 * 8];  // every wave's own end of the PU phase
 #define SUBPEL_STAMP(i)                                                                                          \
     do {                                                                                                         \
         if (tid == 0 && sb < 8192u) g_subpel_stamps[(size_t)sb * 8 + (i)] = __builtin_amdgcn_s_memtime();        \
@@ -385,8 +411,15 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
+#ifdef SVTHIP_SUBPEL_PERSISTENT
+    for (uint32_t vb = blockIdx.x; vb < xcd_grid(n_sb); vb += gridDim.x) {
+    const uint32_t sb = xcd_item(vb, n_sb);
+    if (sb >= n_sb) continue;
+    __syncthreads();  // the previous superblock's readers are done with the planes and the hand-shake words
+#else
     const uint32_t sb = xcd_item(blockIdx.x, n_sb);  // raster neighbours share an XCD's L2 (me_kernels.h)
     if (sb >= n_sb) return;
+#endif
     const int32_t* d = desc + 6 * sb;
     const int src_off = d[0], ref_off = d[1], xo = d[2], yo = d[3], sw = d[4], sh = d[5];
     uint32_t* sad_io = io_sad + (size_t)n_pu * sb;
@@ -422,25 +455,30 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
         Y0 = min(Y0, by - 1);
         Y1 = max(Y1, by + (int)(gm >> 24) + 1);
     }
+    {
+        // the four extremes as two packed pairs of 16-bit minima (|coordinate| < 2^9): (X0, -X1) and (Y0, -Y1), one v_pk_min_i16 per pair and
+        // step -- 12 cross-lane moves instead of 24 on the serial path every wave walks before anything else can start
+        typedef short v2s16 __attribute__((ext_vector_type(2)));
+        // (a lane without a PU still holds the initial +-0x7fffffff: clamped to 32000, it changes no minimum)
+        v2s16 px = {(short)min(X0, 32000), (short)min(-X1, 32000)}, py = {(short)min(Y0, 32000), (short)min(-Y1, 32000)};
 #pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-        X0 = min(X0, __shfl_xor(X0, sft));
-        X1 = max(X1, __shfl_xor(X1, sft));
-        Y0 = min(Y0, __shfl_xor(Y0, sft));
-        Y1 = max(Y1, __shfl_xor(Y1, sft));
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            px = __builtin_elementwise_min(px, __builtin_bit_cast(v2s16, __shfl_xor(__builtin_bit_cast(int, px), sft)));
+            py = __builtin_elementwise_min(py, __builtin_bit_cast(v2s16, __shfl_xor(__builtin_bit_cast(int, py), sft)));
+        }
+        X0 = px.x; X1 = -(int)px.y; Y0 = py.x; Y1 = -(int)py.y;
     }
     // clamp to what the planes hold (a vector outside its search area would be a caller error; never index outside the LDS)
     X0 = __builtin_amdgcn_readfirstlane(max(X0, -1));
     X1 = __builtin_amdgcn_readfirstlane(min(X1, sw + 64));
     Y0 = __builtin_amdgcn_readfirstlane(max(Y0, -1));
     Y1 = __builtin_amdgcn_readfirstlane(min(Y1, sh + 64));
-    // dword columns of the b / h / j planes to fill (plane column = x + 1) and rows.  Rows go to waves, dword columns to lanes (two rows
-    // per wave pass when a row is at most 32 dwords): no integer division, coalesced row reads, loads of four rows in flight per lane.
+    // dword columns of the b / h / j planes to fill (plane column = x + 1) and rows.  Every phase walks ONE flat list of (row, dword
+    // column) items, thread t taking items t, t + threads, ...: the typical box is ~72 samples = 18 dword columns wide, and rows-to-waves
+    // with columns-to-lanes (round 2) kept 36 of 64 lanes busy and needed 5 + 5 + 5 wave passes where the flat lists need 6 + 3.  Row of an
+    // item by a reciprocal multiply (exact: items < 2^14, columns <= 51, so item * (columns - 1) < 2^20).
     SUBPEL_STAMP(1);
     const int c0 = (X0 + 1) >> 2, c1 = (X1 + 1) >> 2, ncol = c1 - c0 + 1;
-    const int two = ncol + 1 <= 32 ? 1 : 0;                     // A rows are ncol + 1 dwords
-    const int cc = c0 + (two ? (lane & 31) : lane), rsub = two ? (lane >> 5) : 0, rstep = n_waves << two;
-    const int rfirst = (wave << two) + rsub;
 #ifdef SVTHIP_SUBPEL_EXPERIMENT_NO_PLANES  // timing experiments only (tools/build_variant.sh): results are wrong
     if (false) {
 #else
@@ -451,54 +489,59 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
             const uint8_t* base = ref_plane + ref_off - 3;  // plane column 0 = x = -3
             const int ra0 = Y0 - 2, nra = Y1 - Y0 + 4;
             // the dword right of the last needed column may not exist in the plane (only don't-care b samples read it)
-            const bool col_ok = cc <= c1 + 1 && 4 * cc < P.PA;
-            for (int r0 = rfirst; r0 < nra; r0 += 4 * rstep) {
-                // one dword per lane at the window's own byte alignment (global loads need no alignment on this target)
+            const int ncol_a = min(ncol + 1, (P.PA >> 2) - c0);
+            const uint32_t inv_a = ((1u << 20) + (uint32_t)ncol_a - 1u) / (uint32_t)ncol_a;
+            const int n_a = nra * ncol_a;
+            for (int i0 = tid; i0 < n_a; i0 += 4 * nthr) {
+                // one dword per lane at the window's own byte alignment (global loads need no alignment on this target), four in flight
                 struct __attribute__((packed, aligned(1))) u1 { uint32_t v; };
                 uint32_t val[4];
+                int at[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int rr = r0 + u * rstep;
-                    if (rr < nra && col_ok)
+                    const int i = i0 + u * nthr;
+                    const int rr = (int)(((uint32_t)i * inv_a) >> 20), cc = c0 + i - rr * ncol_a;
+                    at[u] = ((ra0 + rr + 3) * P.PA >> 2) + cc;
+                    if (i < n_a)
                         val[u] = ((const __attribute__((address_space(1))) u1*)reinterpret_cast<uintptr_t>(base + (int64_t)(ra0 + rr) * ref_stride + 4 * cc))->v;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int rr = r0 + u * rstep;
-                    if (rr < nra && col_ok) reinterpret_cast<lds_u32*>(P.A + (ra0 + rr + 3) * P.PA)[cc] = val[u];
-                }
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * nthr < n_a) reinterpret_cast<lds_u32*>(P.A)[at[u]] = val[u];
             }
         }
         __syncthreads();
         SUBPEL_STAMP(2);
-        // ---- b rows Y0 - 2 .. Y1 + 1 and h rows Y0 .. Y1 ----
-        if (cc <= c1) {
-            const int nrb = Y1 - Y0 + 4;
-            for (int rr = rfirst; rr < nrb; rr += rstep) {
-                const int y = Y0 - 2 + rr;
-                const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y + 3) * P.PA) + cc;  // A(x - 2 ..) for x = 4 cc - 1: plane column 4 cc
-                const uint32_t e0 = q[0], e1 = q[1];
-                reinterpret_cast<lds_u32*>(P.B + (y + 3) * P.PB)[cc] = hfilt1(e0) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 8) |
-                                                                      (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 2)) << 16) |
-                                                                      (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 3)) << 24);
-            }
-            const int nrh = Y1 - Y0 + 1;
-            for (int rr = rfirst; rr < nrh; rr += rstep) {
-                const int y = Y0 + rr;
-                // h(x, y) from A(x, y - 2 .. y + 1), x = 4 cc - 1 .. 4 cc + 2: A plane column 4 cc + 2 = dwords cc, cc + 1 shifted by 2 bytes
-                const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y - 2 + 3) * P.PA) + cc;
-                const int pa4 = P.PA >> 2;
-                reinterpret_cast<lds_u32*>(P.H + (y + 1) * P.PB)[cc] =
-                    vfilt4(__builtin_amdgcn_alignbyte(q[1], q[0], 2), __builtin_amdgcn_alignbyte(q[pa4 + 1], q[pa4], 2),
-                           __builtin_amdgcn_alignbyte(q[2 * pa4 + 1], q[2 * pa4], 2), __builtin_amdgcn_alignbyte(q[3 * pa4 + 1], q[3 * pa4], 2));
+        const uint32_t inv_c = ((1u << 20) + (uint32_t)ncol - 1u) / (uint32_t)ncol;
+        // ---- b rows Y0 - 2 .. Y1 + 1, then h rows Y0 .. Y1, as one list ----
+        {
+            const int nrb = Y1 - Y0 + 4, nrh = Y1 - Y0 + 1, n_bh = (nrb + nrh) * ncol, pa4 = P.PA >> 2;
+            for (int i = tid; i < n_bh; i += nthr) {
+                const int rr = (int)(((uint32_t)i * inv_c) >> 20), cc = c0 + i - rr * ncol;
+                if (rr < nrb) {
+                    const int y = Y0 - 2 + rr;
+                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y + 3) * P.PA) + cc;  // A(x - 2 ..) for x = 4 cc - 1: plane column 4 cc
+                    const uint32_t e0 = q[0], e1 = q[1];
+                    reinterpret_cast<lds_u32*>(P.B + (y + 3) * P.PB)[cc] = hfilt1(e0) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 8) |
+                                                                          (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 2)) << 16) |
+                                                                          (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 3)) << 24);
+                } else {
+                    const int y = Y0 + rr - nrb;
+                    // h(x, y) from A(x, y - 2 .. y + 1), x = 4 cc - 1 .. 4 cc + 2: A plane column 4 cc + 2 = dwords cc, cc + 1 shifted by 2 bytes
+                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y - 2 + 3) * P.PA) + cc;
+                    reinterpret_cast<lds_u32*>(P.H + (y + 1) * P.PB)[cc] =
+                        vfilt4(__builtin_amdgcn_alignbyte(q[1], q[0], 2), __builtin_amdgcn_alignbyte(q[pa4 + 1], q[pa4], 2),
+                               __builtin_amdgcn_alignbyte(q[2 * pa4 + 1], q[2 * pa4], 2), __builtin_amdgcn_alignbyte(q[3 * pa4 + 1], q[3 * pa4], 2));
+                }
             }
         }
         __syncthreads();
         SUBPEL_STAMP(3);
         // ---- j rows Y0 .. Y1 from the ROUNDED b rows y - 2 .. y + 1 ----
-        if (cc <= c1) {
-            const int nrh = Y1 - Y0 + 1, pb4 = P.PB >> 2;
-            for (int rr = rfirst; rr < nrh; rr += rstep) {
+        {
+            const int nrh = Y1 - Y0 + 1, pb4 = P.PB >> 2, n_j = nrh * ncol;
+            for (int i = tid; i < n_j; i += nthr) {
+                const int rr = (int)(((uint32_t)i * inv_c) >> 20), cc = c0 + i - rr * ncol;
                 const int y = Y0 + rr;
                 const lds_u32* q = reinterpret_cast<const lds_u32*>(P.B + (y - 2 + 3) * P.PB) + cc;
                 reinterpret_cast<lds_u32*>(P.J + (y + 1) * P.PB)[cc] = vfilt4(q[0], q[pb4], q[2 * pb4], q[3 * pb4]);
@@ -520,41 +563,61 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.shake = ctl + 4;
     c.lane = lane;
     c.method = __builtin_amdgcn_readfirstlane(method);
-#ifdef SVTHIP_SUBPEL_EXPERIMENT_NO_PU
-    const int n_tasks = 0;
-#else
-    const int n_tasks = n_pu == 209 ? 28 : 8;
-#endif
+#ifndef SVTHIP_SUBPEL_EXPERIMENT_NO_PU
+    const uint16_t* tasks = n_pu == 209 ? kTasks209[wave < 7 ? wave : 0] : kTasks85[wave & 7];
+    const int max_tasks = (n_pu == 209 ? 6 : 4) * ((n_pu == 209 ? wave < 7 : wave < 8) ? 1 : 0);
 #pragma unroll 1
-    for (int task = wave; task < n_tasks; task += n_waves) {
-        const int cls = __builtin_amdgcn_readfirstlane(task >> 1), half = task & 1;
+    for (int k = 0; k < max_tasks; k++) {
+        const int t = __builtin_amdgcn_readfirstlane((int)tasks[k]);
+        if (t == 0xffff) break;
+        const int cls = t & 15, half = (t >> 4) & 1, u_first = (t >> 5) & 3, u_count = (t >> 7) & 7;
         const bool refine = !(cls == 3 && disable_8x8);
         switch (cls) {
-        case 0: run_class<0>(c, half, refine); break;
-        case 1: run_class<1>(c, half, refine); break;
-        case 2: run_class<2>(c, half, refine); break;
-        case 3: run_class<3>(c, half, refine); break;
-        case 4: run_class<4>(c, half, refine); break;
-        case 5: run_class<5>(c, half, refine); break;
-        case 6: run_class<6>(c, half, refine); break;
-        case 7: run_class<7>(c, half, refine); break;
-        case 8: run_class<8>(c, half, refine); break;
-        case 9: run_class<9>(c, half, refine); break;
-        case 10: run_class<10>(c, half, refine); break;
-        case 11: run_class<11>(c, half, refine); break;
-        case 12: run_class<12>(c, half, refine); break;
-        default: run_class<13>(c, half, refine); break;
+        case 0: run_class<0>(c, half, refine, u_first, u_count); break;
+        case 1: run_class<1>(c, half, refine, u_first, u_count); break;
+        case 2: run_class<2>(c, half, refine, u_first, u_count); break;
+        case 3: run_class<3>(c, half, refine, u_first, u_count); break;
+        case 4: run_class<4>(c, half, refine, u_first, u_count); break;
+        case 5: run_class<5>(c, half, refine, u_first, u_count); break;
+        case 6: run_class<6>(c, half, refine, u_first, u_count); break;
+        case 7: run_class<7>(c, half, refine, u_first, u_count); break;
+        case 8: run_class<8>(c, half, refine, u_first, u_count); break;
+        case 9: run_class<9>(c, half, refine, u_first, u_count); break;
+        case 10: run_class<10>(c, half, refine, u_first, u_count); break;
+        case 11: run_class<11>(c, half, refine, u_first, u_count); break;
+        case 12: run_class<12>(c, half, refine, u_first, u_count); break;
+        default: run_class<13>(c, half, refine, u_first, u_count); break;
         }
     }
+#endif
     SUBPEL_STAMP(5);
+#ifdef SVTHIP_SUBPEL_STAMPS
+    if (lane == 0 && sb < 8192u) g_subpel_wave_end[(size_t)sb * 8 + wave] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef SVTHIP_SUBPEL_PERSISTENT
+    }
+#endif
 }
 
 #ifdef SVTHIP_SUBPEL_STAMPS
+extern "C" int svthip_debug_subpel_wave_end(void* host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_subpel_wave_end), bytes < sizeof(g_subpel_wave_end) ? bytes : sizeof(g_subpel_wave_end));
+}
 extern "C" int svthip_debug_subpel_stamps(void* host, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_subpel_stamps), bytes < sizeof(g_subpel_stamps) ? bytes : sizeof(g_subpel_stamps));
 }
 #endif
+
+uint32_t subpel_planes_grid(uint32_t n_sb)
+{
+#ifdef SVTHIP_SUBPEL_PERSISTENT
+    return xcd_grid(n_sb) < 512u ? xcd_grid(n_sb) : 512u;
+#else
+    return xcd_grid(n_sb);
+#endif
+}
 
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {

@@ -306,7 +306,7 @@ static int32_t subpel_refine_common(svthip_ctx* ctx, const uint8_t* d_src_plane,
     // of the largest legal area (127 x 127) take 152.6 KB, so every legal call fits
     const size_t lds_planes = svthip::subpel_planes_lds_bytes(max_search_area_width, max_search_area_height);
     if (lds_planes > 160 * 1024 - 512) return fail(SVTHIP_ERR_BAD_PARAMETER, "search area too large for the LDS planes%s", "");
-    hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::xcd_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
+    hipLaunchKernelGGL(svthip::subpel_planes_kernel, dim3(svthip::subpel_planes_grid(n_sb)), dim3(n_pu == 209 ? 448 : 512), lds_planes, s, d_src_plane, src_stride,
                        d_ref_plane, ref_stride, reinterpret_cast<const int32_t*>(d_desc), n_sb, (int)(disable_8x8_refinement != 0), n_pu,
                        d_best_sad, d_best_mv, d_pred, (int)method);
     HIP_TRY(hipGetLastError());

@@ -49,4 +49,12 @@ for n_pu, fp, sub in ((85, ctx.fullpel_search_dev, ctx.subpel_refine_dev), (209,
     print(f"== {n_pu} PUs: launch span {int(st[:, 5].max() - st[:, 0].min())} ticks, {n} workgroups")
     for i, nm in enumerate(names):
         print(f"  {nm:38s} median {np.median(d[:, i]):8.0f}   p10 {np.percentile(d[:, i], 10):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
+    fw = svtav1_hip.lib().svthip_debug_subpel_wave_end
+    fw.restype = C.c_int
+    fw.argtypes = [C.c_void_p, C.c_size_t]
+    we = np.zeros((n, 8), np.uint64)
+    assert fw(we.ctypes.data, we.nbytes) == 0
+    nw = 7 if n_pu == 209 else 8
+    pu = we[:, :nw].astype(np.int64) - st[:, 4:5].astype(np.int64)
+    print("  PU phase per wave (median ticks from the end of the plane phases): " + " ".join(f"{np.median(pu[:, w]):.0f}" for w in range(nw)))
     print(f"  {'whole workgroup (wave 0)':38s} median {np.median(st[:, 5].astype(np.int64) - st[:, 0].astype(np.int64)):8.0f}")
