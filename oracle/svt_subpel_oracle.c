@@ -233,6 +233,13 @@ static const int8_t kQuarter[4][8][2][3] = {
     {{{2, -1, 0}, {3, 0, 0}}, {{3, 0, 0}, {2, 0, 0}}, {{1, 0, -1}, {3, 0, 0}}, {{3, 0, 0}, {1, 0, 0}},
      {{2, -1, 0}, {1, 0, -1}}, {{1, 0, -1}, {2, 0, 0}}, {{1, 0, 0}, {2, 0, 0}}, {{2, -1, 0}, {1, 0, 0}}}};
 
+/* accessor for tests/test_subpel_tables.py: the six numbers of one table entry (buf1 plane, dx, dy, buf2 plane, dx, dy) */
+void orc_quarter_table_entry(int method, int pos, int8_t *out6)
+{
+    for (int b = 0; b < 2; b++)
+        for (int k = 0; k < 3; k++) out6[3 * b + k] = kQuarter[method][pos][b][k];
+}
+
 static const int8_t kQmv[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {1, 1}, {-1, 1}};
 
 static void pu_quarter_pel(const uint8_t *src, int src_stride, const RefView *r, int px, int py, int w, int h, int xo, int yo, int fsm,

@@ -107,10 +107,10 @@ __device__ __forceinline__ uint32_t gsum(uint32_t v)  // sum over the LPP consec
 {
     // inside a 16-lane row the exchange rides on the add as a DPP modifier (quad swaps, then the mirrored half row / row:
     // any pairing of complementary partial sums works for an all-reduce); only the 16- and 32-lane steps go through the LDS crossbar
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);                       // quad_perm [1,0,3,2]
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);                       // quad_perm [2,3,0,1]
-    if constexpr (LPP >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    if constexpr (LPP >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);                       // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);                       // quad_perm [2,3,0,1]
+    if constexpr (LPP >= 8) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    if constexpr (LPP >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
 #pragma unroll
     for (int m = 16; m < LPP; m <<= 1) v += __shfl_xor(v, m);
     return v;

@@ -33,19 +33,34 @@ namespace {
 // planes in LDS, search-region coordinates (x, y): integer sample A(x, y) = ref[ref_off + y * stride + x]
 //   A : x in [-3, sw + 65], y in [-3, sh + 65]        b : x in [-1, sw + 64], y in [-3, sh + 65]
 //   h, j : x in [-1, sw + 64], y in [-1, sh + 64]
+// All four planes have the SAME geometry -- sample (x, y) at byte (y + 3) * pitch + x + 3 of its plane, planes D bytes apart -- so the
+// address of sample (x, y) of plane p is base + p * D + y * pitch + x: one multiply-add instead of a per-plane choice of origin and pitch
+// (b / h / j carry two unused columns and rows; 64 x 64 areas: 74.7 KB instead of 71 KB, still two workgroups per CU).
 // Row pitch: an ODD number of dwords.  A lane reads row r of a cell; the 4 lane groups of a 32-lane LDS pass are cells stacked vertically
 // (rows 8g + r) or side by side (+8 dwords), so with an odd pitch the 32 lanes of a pass fall on 32 different banks.  (A pitch of 4
 // dwords mod 32 was tried: rows 8 apart alias and the groups of one PU collide 4-way, SQ_LDS_BANK_CONFLICT doubled.)
 __host__ __device__ constexpr int subpel_plane_pitch(int cols) { return 4 * (((cols + 3) / 4) | 1); }
 
 struct Planes {
-    lds_u8 *A, *B, *H, *J;
-    int PA, PB;  // pitches (multiples of 4)
-    // byte distances B - A, H - B, J - H: plane_addr selects a plane by ADDING them under compares.  (Selecting among the four pointers
-    // with a chain of ?: was turned by the compiler into an indexed load from a private copy of this struct: 96 bytes of scratch and
-    // ~450 scratch_load sites in the kernel for what are four wave-uniform values.)
-    int dAB, dBH, dHJ;
+    lds_u8* A;      // first byte of plane A = sample (-3, -3); b, h, j follow at D, 2 D, 3 D
+    uint32_t base;  // LDS byte address of plane A's sample (0, 0)
+    int P;          // row pitch in bytes (a multiple of 4)
+    int D;          // plane distance in bytes (a multiple of 16: every plane has the same dword phase)
 };
+
+// The half-pel grid in QUARTER-pel units: a sample at (sx, sy), both even, lives in plane (sx & 2 ? 1 : 0) | (sy & 2) (A: both integer,
+// b: x half, h: y half, j: both) at the index rounded UP to the next integer position (b[x] is the half-pel sample at x - 1/2).  Its LDS
+// address is Planes::base + col_term(sx) + row_term(sy): the plane choice splits into an x part (D) and a y part (2 D).
+__device__ __forceinline__ int col_term(const Planes& P, int sx)
+{
+    const int t = sx & 2;
+    return ((sx + t) >> 2) + (t >> 1) * P.D;
+}
+__device__ __forceinline__ int row_term(const Planes& P, int sy)
+{
+    const int t = sy & 2;
+    return ((sy + t) >> 2) * P.P + t * P.D;
+}
 
 // 8 bytes starting `s` bytes into the aligned dword at LDS address `qa`: three aligned dwords + two v_alignbyte
 __device__ __forceinline__ void rd8(uint32_t qa, uint32_t s, uint32_t& lo, uint32_t& hi)
@@ -90,6 +105,47 @@ constexpr MeGeom make_me_geom()
 }
 __device__ constexpr MeGeom kMeGeom = make_me_geom();
 
+// raster PU index -> ME-buffer index | px << 8 | py << 16 (one load per PU instead of three)
+struct PuPacked {
+    uint32_t v[209];
+};
+constexpr PuPacked make_pu_packed()
+{
+    PuPacked t{};
+    for (int i = 0; i < 209; i++) t.v[i] = (uint32_t)kPu.me[i] | ((uint32_t)kPu.px[i] << 8) | ((uint32_t)kPu.py[i] << 16);
+    return t;
+}
+__device__ constexpr PuPacked kPuPacked = make_pu_packed();
+
+// Quarter-pel positions (bits L, R, T, B, TL, TR, BR, BL = 0..7) tried next to the winning half-pel direction (:2859-2881; a best vector
+// that sits on a half-pel position uses the mirrored set), one byte per direction in the order the reference tests for the first match:
+// L, R, T, B, TL, TR, BL, BR (:2209-2238) -- the rank that the keyed minimum in refine_class_half delivers.
+constexpr uint64_t make_quarter_valid(bool mirrored)
+{
+    const int dir_of_rank[8] = {DIR_L, DIR_R, DIR_T, DIR_B, DIR_TL, DIR_TR, DIR_BL, DIR_BR};
+    uint64_t tab = 0;
+    for (int rank = 0; rank < 8; rank++) {
+        const int d = dir_of_rank[rank];
+        bool v[8] = {};
+        if (mirrored) {
+            v[4] = (d == DIR_R || d == DIR_BR || d == DIR_B);  v[2] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
+            v[5] = (d == DIR_B || d == DIR_BL || d == DIR_L);  v[1] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
+            v[6] = (d == DIR_L || d == DIR_TL || d == DIR_T);  v[3] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
+            v[7] = (d == DIR_T || d == DIR_TR || d == DIR_R);  v[0] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
+        } else {
+            v[4] = (d == DIR_L || d == DIR_TL || d == DIR_T);  v[2] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
+            v[5] = (d == DIR_T || d == DIR_TR || d == DIR_R);  v[1] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
+            v[6] = (d == DIR_R || d == DIR_BR || d == DIR_B);  v[3] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
+            v[7] = (d == DIR_B || d == DIR_BL || d == DIR_L);  v[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
+        }
+        uint64_t m = 0;
+        for (int k = 0; k < 8; k++) m |= v[k] ? (1ull << k) : 0ull;
+        tab |= m << (8 * rank);
+    }
+    return tab;
+}
+constexpr uint64_t kQuarterValid0 = make_quarter_valid(false), kQuarterValid1 = make_quarter_valid(true);
+
 struct Ctx {
     const uint8_t* src;   // SB top-left in the source plane
     uint32_t src_stride;
@@ -101,15 +157,6 @@ struct Ctx {
     int lane;
     int method;                // MeContext_t::fractionalSearchMethod: 0 SUB_SAD_SEARCH, 1 FULL_SAD_SEARCH, 2 SSD_SEARCH (wave-uniform)
 };
-
-// LDS byte address of plane p at search coordinates (x, y), and that plane's pitch
-__device__ __forceinline__ uint32_t plane_addr(const Planes& P, int p, int x, int y, int& pitch)
-{
-    const int off = (p >= 1 ? P.dAB : 0) + (p >= 2 ? P.dBH : 0) + (p >= 3 ? P.dHJ : 0);
-    pitch = p == 0 ? P.PA : P.PB;
-    const int oy = p <= 1 ? 3 : 1, ox = p == 0 ? 3 : 1;
-    return (uint32_t)reinterpret_cast<uintptr_t>((const lds_u8*)P.A) + (uint32_t)(off + (y + oy) * pitch + x + ox);
-}
 
 // All PUs of one class, 16 chunks of 4 cells, chunks [8 * half, 8 * half + 8) on this wave: lane group g = lane >> 3 owns chunk
 // 8 * half + g, lane & 7 = the row inside a cell.  The 4 cells of a chunk sit at compile-time offsets from the chunk's first cell
@@ -127,7 +174,7 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
     constexpr int LPP = 8 * GPP;
     constexpr bool TWO_WAVES = CPP > 32;                           // 64x64: the other half of the PU is on the partner wave
     const int g = c.lane >> 3, r = c.lane & 7, chunk = 8 * half + g;
-    const int pa8 = 8 * c.P.PA, pb8 = 8 * c.P.PB;
+    const int p8 = 8 * c.P.P;
     // u_first / u_count: the slice of the chunk's UNITS PUs this task covers (classes with one PU per chunk: 0 / 1)
 #pragma unroll 1
     for (int u = (UNITS > 1 ? u_first : 0); u < (UNITS > 1 ? u_first + u_count : 1); u++) {
@@ -135,7 +182,8 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
         const int pu_in_class = CPP >= 4 ? chunk / CQ : chunk * UNITS + u;
         const int cell0 = CPP >= 4 ? (chunk % CQ) * 4 : 0;
         const int cx0 = cell0 % CW, cy0 = cell0 / CW;
-        const int pu = kClass[CLS].base + pu_in_class, me = kPu.me[pu], px = kPu.px[pu], py = kPu.py[pu];
+        const uint32_t ppk = kPuPacked.v[kClass[CLS].base + pu_in_class];
+        const int me = (int)(ppk & 255u), px = (int)((ppk >> 8) & 255u), py = (int)(ppk >> 16);
         uint32_t best_sad = c.sad_io[me], best_mv = c.mv_io[me], best_ssd = 0;
         const uint8_t* srow = c.src + (size_t)(py + 8 * cy0 + r) * c.src_stride + px + 8 * cx0;  // row r of the chunk's first cell
         const size_t s8 = 8 * (size_t)c.src_stride;
@@ -148,25 +196,23 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
             for (int k = 0; k < 9; k++) ssd[k] = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) sad[k] = 0;
-            int pt;
-            const uint32_t aA = plane_addr(c.P, 0, bx, by, pt), aB = plane_addr(c.P, 1, bx, by, pt), aH = plane_addr(c.P, 2, bx, by, pt),
-                           aJ = plane_addr(c.P, 3, bx, by, pt);
-            const uint32_t sA = aA & 3u, sB = aB & 3u;  // b, h, j share their geometry: one shift
-            const uint32_t qA = aA & ~3u, qB = aB & ~3u, qH = aH & ~3u, qJ = aJ & ~3u;
+            // the four planes share their geometry: one address, one byte shift, the planes D apart
+            const uint32_t aA = c.P.base + (uint32_t)(by * c.P.P + bx);
+            const uint32_t sA = aA & 3u, qA = aA & ~3u, qB = qA + (uint32_t)c.P.D, qH = qB + (uint32_t)c.P.D, qJ = qH + (uint32_t)c.P.D;
 #pragma unroll
             for (int ci = 0; ci < CPU; ci++) {
                 constexpr int dummy = 0;
                 (void)dummy;
                 const int dx = CW >= 4 ? ci : (CW == 2 ? (ci & 1) : 0), dy = CW >= 4 ? 0 : (CW == 2 ? (ci >> 1) : ci);
                 const uint2 sv = *reinterpret_cast<const uint2*>(srow + dy * s8 + 8 * dx);
-                const uint32_t oa = 8 * dx + dy * pa8, ob = 8 * dx + dy * pb8;
+                const uint32_t oa = 8 * dx + dy * p8;
                 uint32_t cand[9][2];  // L, R, T, B, TL, TR, BR, BL, full
                 rd8(qA + oa, sA, cand[8][0], cand[8][1]);
-                rd8x2(qB + ob, sB, cand[0][0], cand[0][1], cand[1][0], cand[1][1]);
-                rd8(qH + ob, sB, cand[2][0], cand[2][1]);
-                rd8(qH + ob + c.P.PB, sB, cand[3][0], cand[3][1]);
-                rd8x2(qJ + ob, sB, cand[4][0], cand[4][1], cand[5][0], cand[5][1]);
-                rd8x2(qJ + ob + c.P.PB, sB, cand[7][0], cand[7][1], cand[6][0], cand[6][1]);
+                rd8x2(qB + oa, sA, cand[0][0], cand[0][1], cand[1][0], cand[1][1]);
+                rd8(qH + oa, sA, cand[2][0], cand[2][1]);
+                rd8(qH + oa + c.P.P, sA, cand[3][0], cand[3][1]);
+                rd8x2(qJ + oa, sA, cand[4][0], cand[4][1], cand[5][0], cand[5][1]);
+                rd8x2(qJ + oa + c.P.P, sA, cand[7][0], cand[7][1], cand[6][0], cand[6][1]);
                 // the SSD leaf is keyed by width: 8-wide PUs are compared on their top 8 rows only (quirk 11); SAD covers all rows
                 const bool in_ssd = (W != 8) || (cy0 + dy == 0);
 #pragma unroll
@@ -222,49 +268,45 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
                     }
                 }
             }
-            uint32_t m = ssd[0];
-#pragma unroll
-            for (int k = 1; k < 8; k++) m = ssd[k] < m ? ssd[k] : m;
-            // first match in the order L, R, T, B, TL, TR, BL, BR (:2209-2238)
-            const int d = (m == ssd[0]) ? DIR_L : (m == ssd[1]) ? DIR_R : (m == ssd[2]) ? DIR_T : (m == ssd[3]) ? DIR_B
-                        : (m == ssd[4]) ? DIR_TL : (m == ssd[5]) ? DIR_TR : (m == ssd[7]) ? DIR_BL : DIR_BR;
+            // Winning direction = the first minimum in the order L, R, T, B, TL, TR, BL, BR (:2209-2238): one keyed minimum,
+            // (distortion << 3) | rank -- a distortion is < 2^27 (64x64: 4096 x 128^2 = 2^26) -- instead of a minimum and a chain of
+            // compares, which the compiler turned into eight nested exec-mask regions.
+            uint32_t rank;
+            {
+                const uint32_t k01 = min((ssd[0] << 3) | 0u, (ssd[1] << 3) | 1u), k23 = min((ssd[2] << 3) | 2u, (ssd[3] << 3) | 3u);
+                const uint32_t k45 = min((ssd[4] << 3) | 4u, (ssd[5] << 3) | 5u), k67 = min((ssd[7] << 3) | 6u, (ssd[6] << 3) | 7u);
+                rank = min(min(k01, k23), min(k45, k67)) & 7u;
+            }
 
             // ---- quarter-pel: the three positions next to the winning half-pel direction, true SSD and SAD ----
             const int hx = (int)(int16_t)(best_mv & 0xffffu), hy = (int)(int16_t)(best_mv >> 16);
-            const int xs = ((hx + 2) >> 2) - c.xo + px + 8 * cx0, ys = ((hy + 2) >> 2) - c.yo + py + 8 * cy0 + r;  // :2847-2848 (+ cell, row)
             const int method = (hy & 2) + ((hx & 2) >> 1);
-            // valid positions (L, R, T, B, TL, TR, BR, BL = bits 0..7) per direction, :2859-2881; `method != 0` uses the mirrored set
-            uint32_t vmask;
-            {
-                bool v[8];
-                if (method) {
-                    v[4] = (d == DIR_R || d == DIR_BR || d == DIR_B);  v[2] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
-                    v[5] = (d == DIR_B || d == DIR_BL || d == DIR_L);  v[1] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
-                    v[6] = (d == DIR_L || d == DIR_TL || d == DIR_T);  v[3] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
-                    v[7] = (d == DIR_T || d == DIR_TR || d == DIR_R);  v[0] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
-                } else {
-                    v[4] = (d == DIR_L || d == DIR_TL || d == DIR_T);  v[2] = (d == DIR_TL || d == DIR_T || d == DIR_TR);
-                    v[5] = (d == DIR_T || d == DIR_TR || d == DIR_R);  v[1] = (d == DIR_TR || d == DIR_R || d == DIR_BR);
-                    v[6] = (d == DIR_R || d == DIR_BR || d == DIR_B);  v[3] = (d == DIR_BR || d == DIR_B || d == DIR_BL);
-                    v[7] = (d == DIR_B || d == DIR_BL || d == DIR_L);  v[0] = (d == DIR_BL || d == DIR_L || d == DIR_TL);
-                }
-                vmask = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) vmask |= v[k] ? (1u << k) : 0u;
-            }
-            // per candidate: the two source rows (plane, offset) resolved ONCE for row r of the chunk's first cell
+            // valid positions (L, R, T, B, TL, TR, BR, BL = bits 0..7) of that direction, :2859-2881; `method != 0` uses the mirrored set
+            uint32_t vmask = (uint32_t)((method ? kQuarterValid1 : kQuarterValid0) >> (8u * rank)) & 0xffu;
+            // Per candidate the two samples whose rounded mean is the quarter-pel sample (SetQuarterPelRefinementInputsOnTheFly,
+            // :3271-3323), resolved ONCE for row r of the chunk's first cell.  The reference's 4 x 8 x 2 table is the H.264 rule and is
+            // computed instead of looked up (a dependent table read per candidate sat in the middle of every PU): with the best half-pel
+            // point (hx, hy) and the candidate (hx + qdx, hy + qdy), the pair is {(hx, hy), (hx + 2 qdx, hy + 2 qdy)} -- the two
+            // neighbours along the odd axis, or the diagonal -- except that a diagonal candidate of a point with hx, hy both integer or
+            // both half takes the other diagonal, {(hx, hy + 2 qdy), (hx + 2 qdx, hy)}.  (tests/test_subpel_tables.py compares the rule
+            // with the reference's table entry by entry.)
+            const int HX = 4 * (px + 8 * cx0 - c.xo) + hx, HY = 4 * (py + 8 * cy0 + r - c.yo) + hy;  // this lane's row, quarter units
+            const int cx_0 = col_term(c.P, HX), cy_0 = row_term(c.P, HY);
+            const bool same_phase = ((hx ^ hy) & 2) == 0;
             int qk[3];
-            uint32_t qa1[3], qs1[3], qp1[3], qa2[3], qs2[3], qp2[3];
+            uint32_t qa1[3], qs1[3], qa2[3], qs2[3];
 #pragma unroll
             for (int t = 0; t < 3; t++) {  // ascending position index = the reference's evaluation order
                 qk[t] = __builtin_ctz(vmask);
                 vmask &= vmask - 1;
-                const int q1 = kQuarter[method][qk[t]][0], q2 = kQuarter[method][qk[t]][1];
-                int p1, p2;
-                const uint32_t a1 = plane_addr(c.P, q1 & 3, xs + ((q1 >> 2) & 3) - 1, ys + ((q1 >> 4) & 3) - 1, p1);
-                const uint32_t a2 = plane_addr(c.P, q2 & 3, xs + ((q2 >> 2) & 3) - 1, ys + ((q2 >> 4) & 3) - 1, p2);
-                qa1[t] = a1 & ~3u; qs1[t] = a1 & 3u; qp1[t] = 8 * p1;
-                qa2[t] = a2 & ~3u; qs2[t] = a2 & 3u; qp2[t] = 8 * p2;
+                // L, R, T, B, TL, TR, BR, BL: dx = {-1, 1, 0, 0, -1, 1, 1, -1}, dy = {0, 0, -1, 1, -1, -1, 1, 1}, two bits each (+1)
+                const int qdx = (int)((0x2858u >> (2 * qk[t])) & 3u) - 1, qdy = (int)((0xA085u >> (2 * qk[t])) & 3u) - 1;
+                const int cx_n = col_term(c.P, HX + 2 * qdx), cy_n = row_term(c.P, HY + 2 * qdy);
+                const bool cross = same_phase && qdx != 0 && qdy != 0;
+                const uint32_t a1 = c.P.base + (uint32_t)(cx_0 + (cross ? cy_n : cy_0));
+                const uint32_t a2 = c.P.base + (uint32_t)(cx_n + (cross ? cy_0 : cy_n));
+                qa1[t] = a1 & ~3u; qs1[t] = a1 & 3u;
+                qa2[t] = a2 & ~3u; qs2[t] = a2 & 3u;
             }
             uint32_t qssd[3] = {0, 0, 0}, qsad[3] = {0, 0, 0}, qsv[3] = {0, 0, 0}, qsrc2 = 0;
 #pragma unroll
@@ -277,8 +319,8 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
                     uint32_t a0, a1, b0, b1;
-                    rd8(qa1[t] + 8 * dx + dy * qp1[t], qs1[t], a0, a1);
-                    rd8(qa2[t] + 8 * dx + dy * qp2[t], qs2[t], b0, b1);
+                    rd8(qa1[t] + 8 * dx + dy * p8, qs1[t], a0, a1);
+                    rd8(qa2[t] + 8 * dx + dy * p8, qs2[t], b0, b1);
                     const uint32_t v0 = avg_u8x4(a0, b0), v1 = avg_u8x4(a1, b1);
                     // CombinedAveragingSSD: true SSD (:2792-2817) = sum s^2 (shared by the three candidates) + sum v^2 - 2 sum s v
                     qssd[t] = __builtin_amdgcn_udot4(v1, v1, __builtin_amdgcn_udot4(v0, v0, qssd[t], false), false);
@@ -333,19 +375,22 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
         if (c.pred) {
             // the prediction block at the final MV as BiPredictionCompensation builds it (kBiFrac), for the stored-prediction bi-pred
             const int fx = (int)(int16_t)(best_mv & 0xffffu), fy = (int)(int16_t)(best_mv >> 16);
-            const int f = (fx & 3) + ((fy & 3) << 2);
-            const int e0 = kBiFrac[f][0], e1 = kBiFrac[f][1];
-            const int ix = (fx >> 2) - c.xo + px + 8 * cx0, iy = (fy >> 2) - c.yo + py + 8 * cy0 + r;
-            int p1, p2;
-            const uint32_t a1 = plane_addr(c.P, e0 & 3, ix + ((e0 >> 2) & 1), iy + ((e0 >> 3) & 1), p1);
-            const uint32_t a2 = plane_addr(c.P, e1 & 3, ix + ((e1 >> 2) & 1), iy + ((e1 >> 3) & 1), p2);
+            // the same rule for any final vector: an even coordinate keeps its column / row, an odd one takes its two neighbours, the one
+            // on the half-pel grid (== 2 mod 4) and the one on the integer grid; a diagonal pairs (half, integer) with (integer, half)
+            const int FX = 4 * (px + 8 * cx0 - c.xo) + fx, FY = 4 * (py + 8 * cy0 + r - c.yo) + fy;
+            const int ux = 1 - (FX & 2), uy = 1 - (FY & 2);
+            const bool ox = FX & 1, oy = FY & 1;
+            const int x1 = ox ? FX + ux : FX, x2 = ox ? FX - ux : FX;
+            const int y1 = oy ? (ox ? FY - uy : FY + uy) : FY, y2 = oy ? (ox ? FY + uy : FY - uy) : FY;
+            const uint32_t a1 = c.P.base + (uint32_t)(col_term(c.P, x1) + row_term(c.P, y1));
+            const uint32_t a2 = c.P.base + (uint32_t)(col_term(c.P, x2) + row_term(c.P, y2));
             uint32_t* out = c.pred + CLS * 1024 + pu_in_class * (W * H / 4) + ((8 * cy0 + r) * W + 8 * cx0) / 4;
 #pragma unroll
             for (int ci = 0; ci < CPU; ci++) {
                 const int dx = CW >= 4 ? ci : (CW == 2 ? (ci & 1) : 0), dy = CW >= 4 ? 0 : (CW == 2 ? (ci >> 1) : ci);
                 uint32_t a0, a1h, b0, b1;
-                rd8((a1 & ~3u) + 8 * dx + dy * 8 * p1, a1 & 3u, a0, a1h);
-                rd8((a2 & ~3u) + 8 * dx + dy * 8 * p2, a2 & 3u, b0, b1);
+                rd8((a1 & ~3u) + 8 * dx + dy * p8, a1 & 3u, a0, a1h);
+                rd8((a2 & ~3u) + 8 * dx + dy * p8, a2 & 3u, b0, b1);
                 uint2 v;
                 v.x = avg_u8x4(a0, b0);
                 v.y = avg_u8x4(a1h, b1);
@@ -410,7 +455,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
                                                             int method)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, n_waves = nthr >> 6;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
 #ifdef SVTHIP_SUBPEL_PERSISTENT
     for (uint32_t vb = blockIdx.x; vb < xcd_grid(n_sb); vb += gridDim.x) {
     const uint32_t sb = xcd_item(vb, n_sb);
@@ -425,20 +470,24 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     uint32_t* sad_io = io_sad + (size_t)n_pu * sb;
     uint32_t* mv_io = io_mv + (size_t)n_pu * sb;
 
-    // LDS: [bbox 4 ints + shake 25 words -> 128 B][A][b][h][j]
+    // LDS: [4 spare words + hand-shake 25 words -> 128 B][A][b][h][j]
     lds_u32* ctl = (lds_u32*)smem;
     Planes P;
-    P.PA = subpel_plane_pitch(sw + 69);
-    P.PB = subpel_plane_pitch(sw + 66);
-    const int rows_a = sh + 69, rows_h = sh + 66;
+    P.P = subpel_plane_pitch(sw + 69);
+    const int rows_a = sh + 69;
     P.A = (lds_u8*)smem + 128;
-    P.B = P.A + ((P.PA * rows_a + 15) & ~15);
-    P.H = P.B + ((P.PB * rows_a + 15) & ~15);
-    P.J = P.H + ((P.PB * rows_h + 15) & ~15);
-    P.dAB = (P.PA * rows_a + 15) & ~15;
-    P.dBH = (P.PB * rows_a + 15) & ~15;
-    P.dHJ = (P.PB * rows_h + 15) & ~15;
+    P.D = (P.P * rows_a + 15) & ~15;
+    P.base = (uint32_t)reinterpret_cast<uintptr_t>(P.A) + (uint32_t)(3 * P.P + 3);
+    lds_u8* const PB = P.A + P.D;
+    lds_u8* const PH = PB + P.D;
+    lds_u8* const PJ = PH + P.D;
 
+    // The plane phases are a chain of short, dependent steps (vectors -> box -> window -> b, h -> j, four barriers) that the whole workgroup
+    // waits for, while the PU phase of the CU's other workgroup is a long stream of independent vector work: run the chain at raised wave
+    // priority so that its few instructions issue ahead of that stream instead of queueing behind it (SVTHIP_SUBPEL_NO_PRIO: A/B only).
+#ifndef SVTHIP_SUBPEL_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     SUBPEL_STAMP(0);
     // ---- bounding box of the samples the PUs can touch: x in [bx - 1, bx + W + 1], y in [by - 1, by + H + 1] ----
     // Every wave computes it for itself (two independent coalesced loads per lane, a DPP / bpermute min-max over the wave): no LDS, no
@@ -473,23 +522,23 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     X1 = __builtin_amdgcn_readfirstlane(min(X1, sw + 64));
     Y0 = __builtin_amdgcn_readfirstlane(max(Y0, -1));
     Y1 = __builtin_amdgcn_readfirstlane(min(Y1, sh + 64));
-    // dword columns of the b / h / j planes to fill (plane column = x + 1) and rows.  Every phase walks ONE flat list of (row, dword
-    // column) items, thread t taking items t, t + threads, ...: the typical box is ~72 samples = 18 dword columns wide, and rows-to-waves
-    // with columns-to-lanes (round 2) kept 36 of 64 lanes busy and needed 5 + 5 + 5 wave passes where the flat lists need 6 + 3.  Row of an
-    // item by a reciprocal multiply (exact: items < 2^14, columns <= 51, so item * (columns - 1) < 2^20).
+    // dword columns of the planes to fill (plane column = x + 3: dword w holds x = 4 w - 3 .. 4 w) and rows.  Every phase walks ONE flat
+    // list of (row, dword column) items, thread t taking items t, t + threads, ...: the typical box is ~72 samples = 18 dword columns wide,
+    // and rows-to-waves with columns-to-lanes (round 2) kept 36 of 64 lanes busy and needed 5 + 5 + 5 wave passes where the flat lists need
+    // 6 + 3.  Row of an item by a reciprocal multiply (exact: items < 2^15, columns <= 51, so item * (columns - 1) < 2^20).
     SUBPEL_STAMP(1);
-    const int c0 = (X0 + 1) >> 2, c1 = (X1 + 1) >> 2, ncol = c1 - c0 + 1;
+    const int c0 = (X0 + 3) >> 2, c1 = (X1 + 3) >> 2, ncol = c1 - c0 + 1, p4 = P.P >> 2;
 #ifdef SVTHIP_SUBPEL_EXPERIMENT_NO_PLANES  // timing experiments only (tools/build_variant.sh): results are wrong
     if (false) {
 #else
     if (ncol > 0 && Y1 >= Y0) {
 #endif
-        // ---- A: rows Y0 - 2 .. Y1 + 1, plane dword columns c0 .. c1 + 1 (plane column = x + 3: b's 4 samples at dword c read A dwords c, c + 1) ----
+        // ---- A: rows Y0 - 2 .. Y1 + 1, dword columns c0 - 1 .. c1 + 1 (b's four samples of dword w read A bytes 4 w - 2 .. 4 w + 4) ----
         {
             const uint8_t* base = ref_plane + ref_off - 3;  // plane column 0 = x = -3
             const int ra0 = Y0 - 2, nra = Y1 - Y0 + 4;
-            // the dword right of the last needed column may not exist in the plane (only don't-care b samples read it)
-            const int ncol_a = min(ncol + 1, (P.PA >> 2) - c0);
+            // the dword left of column 0 does not exist and the one right of the last column may not (only don't-care b samples read them)
+            const int ca0 = max(c0 - 1, 0), ncol_a = min(c1 + 1, p4 - 1) - ca0 + 1;
             const uint32_t inv_a = ((1u << 20) + (uint32_t)ncol_a - 1u) / (uint32_t)ncol_a;
             const int n_a = nra * ncol_a;
             for (int i0 = tid; i0 < n_a; i0 += 4 * nthr) {
@@ -500,8 +549,8 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int i = i0 + u * nthr;
-                    const int rr = (int)(((uint32_t)i * inv_a) >> 20), cc = c0 + i - rr * ncol_a;
-                    at[u] = ((ra0 + rr + 3) * P.PA >> 2) + cc;
+                    const int rr = (int)(((uint32_t)i * inv_a) >> 20), cc = ca0 + i - rr * ncol_a;
+                    at[u] = (ra0 + rr + 3) * p4 + cc;
                     if (i < n_a)
                         val[u] = ((const __attribute__((address_space(1))) u1*)reinterpret_cast<uintptr_t>(base + (int64_t)(ra0 + rr) * ref_stride + 4 * cc))->v;
                 }
@@ -515,23 +564,23 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
         const uint32_t inv_c = ((1u << 20) + (uint32_t)ncol - 1u) / (uint32_t)ncol;
         // ---- b rows Y0 - 2 .. Y1 + 1, then h rows Y0 .. Y1, as one list ----
         {
-            const int nrb = Y1 - Y0 + 4, nrh = Y1 - Y0 + 1, n_bh = (nrb + nrh) * ncol, pa4 = P.PA >> 2;
+            const int nrb = Y1 - Y0 + 4, nrh = Y1 - Y0 + 1, n_bh = (nrb + nrh) * ncol;
             for (int i = tid; i < n_bh; i += nthr) {
                 const int rr = (int)(((uint32_t)i * inv_c) >> 20), cc = c0 + i - rr * ncol;
                 if (rr < nrb) {
+                    // b(x, y) from A(x - 2 .. x + 1, y), x = 4 cc - 3 .. 4 cc: A bytes 4 cc - 2 .. 4 cc + 4 of the row = the last two bytes of
+                    // dword cc - 1, dword cc and the first byte of dword cc + 1 (column 0: the bytes before the row feed x = -3, -2 only)
                     const int y = Y0 - 2 + rr;
-                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y + 3) * P.PA) + cc;  // A(x - 2 ..) for x = 4 cc - 1: plane column 4 cc
-                    const uint32_t e0 = q[0], e1 = q[1];
-                    reinterpret_cast<lds_u32*>(P.B + (y + 3) * P.PB)[cc] = hfilt1(e0) | (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 8) |
-                                                                          (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 2)) << 16) |
-                                                                          (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 3)) << 24);
+                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A) + (y + 3) * p4 + cc;
+                    const uint32_t em = q[-1], e0 = q[0], e1 = q[1];
+                    reinterpret_cast<lds_u32*>(PB)[(y + 3) * p4 + cc] =
+                        hfilt1(__builtin_amdgcn_alignbyte(e0, em, 2)) | (hfilt1(__builtin_amdgcn_alignbyte(e0, em, 3)) << 8) | (hfilt1(e0) << 16) |
+                        (hfilt1(__builtin_amdgcn_alignbyte(e1, e0, 1)) << 24);
                 } else {
+                    // h(x, y) from A(x, y - 2 .. y + 1): the same dword column of four rows
                     const int y = Y0 + rr - nrb;
-                    // h(x, y) from A(x, y - 2 .. y + 1), x = 4 cc - 1 .. 4 cc + 2: A plane column 4 cc + 2 = dwords cc, cc + 1 shifted by 2 bytes
-                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A + (y - 2 + 3) * P.PA) + cc;
-                    reinterpret_cast<lds_u32*>(P.H + (y + 1) * P.PB)[cc] =
-                        vfilt4(__builtin_amdgcn_alignbyte(q[1], q[0], 2), __builtin_amdgcn_alignbyte(q[pa4 + 1], q[pa4], 2),
-                               __builtin_amdgcn_alignbyte(q[2 * pa4 + 1], q[2 * pa4], 2), __builtin_amdgcn_alignbyte(q[3 * pa4 + 1], q[3 * pa4], 2));
+                    const lds_u32* q = reinterpret_cast<const lds_u32*>(P.A) + (y - 2 + 3) * p4 + cc;
+                    reinterpret_cast<lds_u32*>(PH)[(y + 3) * p4 + cc] = vfilt4(q[0], q[p4], q[2 * p4], q[3 * p4]);
                 }
             }
         }
@@ -539,16 +588,19 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
         SUBPEL_STAMP(3);
         // ---- j rows Y0 .. Y1 from the ROUNDED b rows y - 2 .. y + 1 ----
         {
-            const int nrh = Y1 - Y0 + 1, pb4 = P.PB >> 2, n_j = nrh * ncol;
+            const int nrh = Y1 - Y0 + 1, n_j = nrh * ncol;
             for (int i = tid; i < n_j; i += nthr) {
                 const int rr = (int)(((uint32_t)i * inv_c) >> 20), cc = c0 + i - rr * ncol;
                 const int y = Y0 + rr;
-                const lds_u32* q = reinterpret_cast<const lds_u32*>(P.B + (y - 2 + 3) * P.PB) + cc;
-                reinterpret_cast<lds_u32*>(P.J + (y + 1) * P.PB)[cc] = vfilt4(q[0], q[pb4], q[2 * pb4], q[3 * pb4]);
+                const lds_u32* q = reinterpret_cast<const lds_u32*>(PB) + (y - 2 + 3) * p4 + cc;
+                reinterpret_cast<lds_u32*>(PJ)[(y + 3) * p4 + cc] = vfilt4(q[0], q[p4], q[2 * p4], q[3 * p4]);
             }
         }
     }
     __syncthreads();
+#ifndef SVTHIP_SUBPEL_NO_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     SUBPEL_STAMP(4);
 
     Ctx c;
@@ -621,10 +673,8 @@ uint32_t subpel_planes_grid(uint32_t n_sb)
 
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
-    const size_t pa = subpel_plane_pitch((int)max_sw + 69), pb = subpel_plane_pitch((int)max_sw + 66);
-    const size_t ra = max_sh + 69, rh = max_sh + 66;
-    auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    return 128 + al(pa * ra) + al(pb * ra) + 2 * al(pb * rh) + 32;  // + slack: the 3-dword reads run up to 11 bytes past a sample
+    const size_t pitch = subpel_plane_pitch((int)max_sw + 69), rows = max_sh + 69;
+    return 128 + 4 * ((pitch * rows + 15) & ~(size_t)15) + 32;  // + slack: the 3-dword reads run up to 11 bytes past a sample
 }
 
 }  // namespace svthip
