@@ -70,49 +70,25 @@ int ref_subpel_search(uint8_t *src00, int src_stride, uint8_t *ref00, int ref_st
         ref00 + (x_search_area_origin - (ME_FILTER_TAP >> 1)) + (ptrdiff_t)(y_search_area_origin - (ME_FILTER_TAP >> 1)) * ref_stride;
     context_ptr->interpolated_full_stride[listIndex][refPicIndex] = (uint32_t)ref_stride;
 
-    /* the result pointers of :6745-6800 */
-    context_ptr->p_best_sad64x64 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x64]);
-    context_ptr->p_best_sad32x32 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x32_0]);
-    context_ptr->p_best_sad16x16 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x16_0]);
-    context_ptr->p_best_sad8x8 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x8_0]);
-    context_ptr->p_best_sad64x32 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x32_0]);
-    context_ptr->p_best_sad32x16 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x16_0]);
-    context_ptr->p_best_sad16x8 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x8_0]);
-    context_ptr->p_best_sad32x64 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x64_0]);
-    context_ptr->p_best_sad16x32 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x32_0]);
-    context_ptr->p_best_sad8x16 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x16_0]);
-    context_ptr->p_best_sad32x8 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x8_0]);
-    context_ptr->p_best_sad8x32 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x32_0]);
-    context_ptr->p_best_sad64x16 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x16_0]);
-    context_ptr->p_best_sad16x64 = &(context_ptr->p_sb_best_sad[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x64_0]);
-    context_ptr->p_best_mv64x64 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x64]);
-    context_ptr->p_best_mv32x32 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x32_0]);
-    context_ptr->p_best_mv16x16 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x16_0]);
-    context_ptr->p_best_mv8x8 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x8_0]);
-    context_ptr->p_best_mv64x32 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x32_0]);
-    context_ptr->p_best_mv32x16 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x16_0]);
-    context_ptr->p_best_mv16x8 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x8_0]);
-    context_ptr->p_best_mv32x64 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x64_0]);
-    context_ptr->p_best_mv16x32 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x32_0]);
-    context_ptr->p_best_mv8x16 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x16_0]);
-    context_ptr->p_best_mv32x8 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x8_0]);
-    context_ptr->p_best_mv8x32 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x32_0]);
-    context_ptr->p_best_mv64x16 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x16_0]);
-    context_ptr->p_best_mv16x64 = &(context_ptr->p_sb_best_mv[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x64_0]);
-    context_ptr->p_best_ssd64x64 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x64]);
-    context_ptr->p_best_ssd32x32 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x32_0]);
-    context_ptr->p_best_ssd16x16 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x16_0]);
-    context_ptr->p_best_ssd8x8 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x8_0]);
-    context_ptr->p_best_ssd64x32 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x32_0]);
-    context_ptr->p_best_ssd32x16 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x16_0]);
-    context_ptr->p_best_ssd16x8 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x8_0]);
-    context_ptr->p_best_ssd32x64 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x64_0]);
-    context_ptr->p_best_ssd16x32 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x32_0]);
-    context_ptr->p_best_ssd8x16 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x16_0]);
-    context_ptr->p_best_ssd32x8 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_32x8_0]);
-    context_ptr->p_best_ssd8x32 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_8x32_0]);
-    context_ptr->p_best_ssd64x16 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_64x16_0]);
-    context_ptr->p_best_ssd16x64 = &(context_ptr->p_sb_best_ssd[listIndex][refPicIndex][ME_TIER_ZERO_PU_16x64_0]);
+    /* the per-shape result pointers MotionEstimateLcu sets up (:6745-6800): for each of the 14 PU shapes, the SAD / MV / SSD pointers are
+     * the three per-(list, reference) result arrays offset by the index of the shape's first PU */
+    {
+        uint32_t *const base_sad = context_ptr->p_sb_best_sad[listIndex][refPicIndex];
+        uint32_t *const base_mv = context_ptr->p_sb_best_mv[listIndex][refPicIndex];
+        uint32_t *const base_ssd = context_ptr->p_sb_best_ssd[listIndex][refPicIndex];
+#define SHAPES(X) \
+    X(64x64, ME_TIER_ZERO_PU_64x64) X(32x32, ME_TIER_ZERO_PU_32x32_0) X(16x16, ME_TIER_ZERO_PU_16x16_0) X(8x8, ME_TIER_ZERO_PU_8x8_0)       \
+    X(64x32, ME_TIER_ZERO_PU_64x32_0) X(32x16, ME_TIER_ZERO_PU_32x16_0) X(16x8, ME_TIER_ZERO_PU_16x8_0) X(32x64, ME_TIER_ZERO_PU_32x64_0)   \
+    X(16x32, ME_TIER_ZERO_PU_16x32_0) X(8x16, ME_TIER_ZERO_PU_8x16_0) X(32x8, ME_TIER_ZERO_PU_32x8_0) X(8x32, ME_TIER_ZERO_PU_8x32_0)       \
+    X(64x16, ME_TIER_ZERO_PU_64x16_0) X(16x64, ME_TIER_ZERO_PU_16x64_0)
+#define BIND(shape, first)                               \
+    context_ptr->p_best_sad##shape = base_sad + (first); \
+    context_ptr->p_best_mv##shape = base_mv + (first);   \
+    context_ptr->p_best_ssd##shape = base_ssd + (first);
+        SHAPES(BIND)
+#undef BIND
+#undef SHAPES
+    }
 
     memcpy(context_ptr->p_sb_best_sad[listIndex][refPicIndex], sad, (size_t)npu * 4);
     memcpy(context_ptr->p_sb_best_mv[listIndex][refPicIndex], mv, (size_t)npu * 4);

@@ -83,6 +83,9 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
     const int n_xg = (sw + 15) >> 4;
     const uint32_t inv_xg = (65536u + (uint32_t)n_xg - 1u) / (uint32_t)n_xg;  // wave-uniform, scalar unit
 
+#ifdef SVTHIP_FP_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     // ---- stage the reference window: rows 0..sh+62, bytes 0..sw+62 valid, zero beyond ----
     {
         // 16 bytes per thread and pass, read at the window's own byte alignment (global loads need no alignment on this target) and
@@ -111,6 +114,9 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
         if (tid == 0) *best64_lds = ~0ull;
     }
     __syncthreads();
+#ifdef SVTHIP_FP_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 
     // source pixels of this wave's quadrant (wave-uniform -> scalar loads)
     const uint32_t* src4 = reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)(32 * Qy) * src_stride + 32 * Qx);

@@ -41,6 +41,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 
 // Optional per-phase time stamps (tools/hme_stamps_probe.py builds a copy of the library with -DSVTHIP_HME_STAMPS): s_memtime of lane 0 of
 // every region wave at the phase boundaries of hme_center_sb, [superblock][wave][8].
+// Wave priority around the latency-bound pieces (source staging, centre checks, window copies); -DSVTHIP_HME_NO_PRIO for A/B timing.
+#ifdef SVTHIP_HME_NO_PRIO
+#define HME_PRIO(p) do { } while (0)
+#else
+#define HME_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 #ifdef SVTHIP_HME_STAMPS
 __device__ unsigned long long g_hme_stamps[8192 * 4 * 8];
 #define HME_STAMP(i)                                                                                                          \
@@ -271,9 +277,11 @@ __device__ void wave_sad_loop_lds(const uint8_t* src, uint32_t src_stride, const
         const int bh = min(band, sh - y0);
         const int wrows = bh + 2 * H - 2;
         HME_LOOP_T(t_a);
+        HME_PRIO(3);  // the window copy is a memory round trip the search below waits for: issue it ahead of the other waves' search loops
         stage_window_rows(ref + (size_t)y0 * ref_stride_raw, ref_stride_raw, wrows, pitch, win, lane);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HME_PRIO(0);
         HME_LOOP_T(t_b);
         HME_LOOP_ADD(0, t_b, t_a);
 
@@ -389,9 +397,11 @@ __device__ void wave_sad_loop_l0(const uint8_t* src, uint32_t src_stride, const 
     const uint32_t inv_nit = (1u << 20) / (uint32_t)nit + 1u;
     for (int y0 = 0; y0 < sh; y0 += band) {
         const int bh = min(band, sh - y0);
+        HME_PRIO(3);
         stage_window_rows(ref + (size_t)y0 * ref_stride_raw, ref_stride_raw, bh + 2 * H - 2, pitch, win, lane);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HME_PRIO(0);
         const int nitems = nit * bh;
         // 16 keys of one item: (sad << 16) + raster index; positions beyond the search width and lanes without an item never win
         auto track = [&](const uint64_t* acc, int iy, int io, bool valid) {
@@ -547,6 +557,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
     const uint8_t* ref_full = pool + ref.full_offset + (size_t)68 * ref.full_stride + 68;
     const uint8_t* src = cur_full + (size_t)oy * cur.full_stride + ox;
     HME_STAMP(0);
+    HME_PRIO(3);  // until the first search loop: staging and the centre checks are a few loads and SADs on the serial path of every level
 
     // full 64x64 SBs: stage the three source blocks once for the whole workgroup (the four region waves search with the same
     // block at every level, and the centre checks compare the same 64 x 32-row block)
@@ -751,6 +762,7 @@ __device__ __forceinline__ void hme_center_sb(const uint8_t* __restrict__ pool, 
     }
 
     // ---- CheckZeroZeroCenter (:5466-5552) ----
+    HME_PRIO(3);
     if ((xc != 0 || yc != 0) && P.is_used_as_reference_flag) {
         clamp_center(xc, yc, ox, oy, ref.width, ref.height);
         __syncthreads();
