@@ -172,7 +172,7 @@ __device__ __forceinline__ void conv_list_tiles(const uint8_t* __restrict__ src,
 // TY = output tiles stacked vertically per wave: they share the IM tile between them (TY + 1 IM tiles instead of 2 TY) and the tap fragments.
 // COMPOUND: descriptors are svthip_convolve_compound_desc, both lists are run and averaged like av1_inter_prediction's BI_PRED path.
 template <int TY, bool COMPOUND>
-__global__ void __launch_bounds__(256) av1_convolve_mfma_kernel(const uint8_t* __restrict__ src0, uint32_t src0_stride, const uint8_t* __restrict__ src1,
+__global__ void __launch_bounds__(256, 2) av1_convolve_mfma_kernel(const uint8_t* __restrict__ src0, uint32_t src0_stride, const uint8_t* __restrict__ src1,
                                                                 uint32_t src1_stride, uint8_t* __restrict__ dst, uint32_t dst_stride,
                                                                 const uint4* __restrict__ desc, uint32_t n_blocks, int w, int h)
 {
