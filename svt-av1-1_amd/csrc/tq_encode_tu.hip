@@ -83,14 +83,40 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
     const Clamp cl_col = {-(1 << 15), (1 << 15) - 1};             // max(bd + 6, 16) = 16 bits for bd 8 and 10
     constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), pix_max = (1 << BD) - 1;
     const uint32_t groups = (n_tu + G - 1) / G;
+    // Square sizes (one round per pass, the same TU on a lane in all three passes): everything the group reads from memory is
+    // requested ONCE, up front -- the descriptor, then in one batch the source / prediction columns, the quantiser row and (sizes up to 16)
+    // the inverse-scan row -- and the prediction samples stay in registers (four per VGPR) for the reconstruction.  Before, every pass
+    // re-read the descriptor and then its own inputs: six dependent memory round trips per group, and with ~4.4 waves per SIMD the counters
+    // showed each wave issuing 15 % of its 42 k-cycle life (profiles/r03_pmc_traffic.json: SQ_WAVE_CYCLES / SQ_WAVES vs SQ_INSTS_VALU).
+    constexpr int PER = 4 / (int)sizeof(PIX), PBITS = 8 * (int)sizeof(PIX);  // prediction samples per kept VGPR
+    constexpr bool HOIST = (W == H) && (sizeof(PIX) == 1 || W <= 32);
+    constexpr bool HOIST_ISCAN = HOIST && W <= 16;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
+        svthip_tu_desc dh{};
+        QParams QPh{};
+        uint32_t ppk[HOIST ? H / PER : 1];
+        short4 isc[HOIST_ISCAN ? W / 4 : 1];
+        if constexpr (HOIST) {
+            const uint32_t tu = grp * G + lane / W;
+            if (tu < n_tu) {
+                dh = desc[tu];
+                QPh = load_qparams(qparams + (size_t)dh.qparam_index * 10, LOG_SCALE);
+                if constexpr (HOIST_ISCAN) {
+                    const int16_t* iscan = iscan_pool + dh.iscan_offset + (lane % H) * WIN;
+#pragma unroll
+                    for (int c = 0; c < W / 4; c++) isc[c] = *reinterpret_cast<const short4*>(iscan + 4 * c);
+                }
+            }
+        }
         // ---- A: residual + forward column pass ----
 #pragma unroll 1
         for (int round = 0; round < ROUNDS_COL; round++) {
             const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
             if (tu < n_tu) {
-                const svthip_tu_desc d = desc[tu];
+                svthip_tu_desc d;
+                if constexpr (HOIST) d = dh;
+                else d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const PIX* s = src + d.src_offset + c;
                 const PIX* p = pred + d.pred_offset + c;
@@ -99,7 +125,9 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
 #pragma unroll
                 for (int r = 0; r < H; r++) {
                     const int rr = (kc == 2 ? H - 1 - r : r);
-                    x[r] = shift_val<SH0>((int32_t)s[rr * ss] - (int32_t)p[rr * ps]);
+                    const int32_t pv = (int32_t)p[rr * ps];
+                    x[r] = shift_val<SH0>((int32_t)s[rr * ss] - pv);
+                    if constexpr (HOIST) ppk[r / PER] = (r % PER) ? (ppk[r / PER] | ((uint32_t)pv << (PBITS * (r % PER)))) : (uint32_t)pv;
                 }
                 txfm1d<H, BITC>(kc, x, y);
                 int32_t* col = tile + g * (H * P) + (kr == 2 ? W - 1 - c : c);
@@ -119,7 +147,9 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
             int64_t energy = 0, dist_res = 0, dist_pred = 0;  // sums of squares: non-negative, below 2^63
             int last = 0;
             if (active) {
-                const svthip_tu_desc d = desc[tu];
+                svthip_tu_desc d;
+                if constexpr (HOIST) d = dh;
+                else d = desc[tu];
                 const int kr = kHtx[d.tx_type & 15];
                 int32_t* row = tile + g * (H * P) + r * P;
                 int32_t x[W], y[W];
@@ -141,14 +171,17 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                     energy = (e4[0] + e4[1]) + (e4[2] + e4[3]);
                 }
                 if (r < HIN) {
-                    const int16_t* qp = qparams + (size_t)d.qparam_index * 10;
-                    const QParams QP = load_qparams(qp, LOG_SCALE);
+                    QParams QP;
+                    if constexpr (HOIST) QP = QPh;
+                    else QP = load_qparams(qparams + (size_t)d.qparam_index * 10, LOG_SCALE);
                     const int16_t* iscan = iscan_pool + d.iscan_offset + r * WIN;
                     const uint32_t base = d.coeff_offset + r * WIN;
                     int32_t dq[W];
 #pragma unroll
                     for (int c = 0; c < WIN; c += 4) {
-                        const short4 is4 = *reinterpret_cast<const short4*>(iscan + c);
+                        short4 is4;
+                        if constexpr (HOIST_ISCAN) is4 = isc[c / 4];
+                        else is4 = *reinterpret_cast<const short4*>(iscan + c);
                         const int isv[4] = {is4.x, is4.y, is4.z, is4.w};
                         int32_t qv[4];
 #pragma unroll
@@ -218,7 +251,9 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
             const int t = round * 64 + lane, g = t / W, c = t % W;
             const uint32_t tu = grp * G + g;
             if (tu < n_tu) {
-                const svthip_tu_desc d = desc[tu];
+                svthip_tu_desc d;
+                if constexpr (HOIST) d = dh;
+                else d = desc[tu];
                 const int kc = kVtx[d.tx_type & 15], kr = kHtx[d.tx_type & 15];
                 const int32_t* col = tile + g * (H * P) + (kr == 2 ? W - 1 - c : c);
                 int32_t x[H], y[H];
@@ -235,7 +270,10 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                     int32_t t = rs<4>((int64_t)y[r]);
                     t = min(max(t, -res_max - 1), res_max);
                     const int rr = flip_row<H>(r, kc);
-                    const int32_t v = (int32_t)p[rr * ps] + t;
+                    int32_t pv;
+                    if constexpr (HOIST) pv = (int32_t)((ppk[r / PER] >> (PBITS * (r % PER))) & ((1u << PBITS) - 1u));  // the sample pass A read for its row r
+                    else pv = (int32_t)p[rr * ps];
+                    const int32_t v = pv + t;
                     out[rr * rs_] = (PIX)min(max(v, 0), pix_max);
                 }
             }
