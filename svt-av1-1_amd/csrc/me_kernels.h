@@ -116,10 +116,10 @@ size_t convolve_compound_lds_bytes(int w, int h);
 const void* convolve_compound_kernel_ptr(int which);  // 0..3
 hipError_t launch_av1_highbd_convolve(const uint16_t* src0, uint32_t src0_stride, const uint16_t* src1, uint32_t src1_stride, uint16_t* dst,
                                       uint32_t dst_stride, const void* desc, bool compound, uint32_t n_blocks, int w, int h, int bd, hipStream_t s);
-size_t sad_loop_qsad_slice_bytes(int w, int h, int sw, int sh, int k);
+size_t sad_loop_qsad_lds_bytes(int w, int h, int sw, int sh, int k);  // workgroup LDS of the packed-SAD kernel (its own plan: blocks per workgroup, pitch)
 hipError_t launch_sad_loop_qsad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t ref_stride_raw,
-                                const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, int slice_bytes,
-                                uint32_t* best_sad, int16_t* best_xy, hipStream_t s);
+                                const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, uint32_t* best_sad,
+                                int16_t* best_xy, hipStream_t s);
 size_t sad_loop_slice_bytes(int w, int h, int sw, int sh, int k);
 bool convolve_size_valid(int w, int h);
 hipError_t launch_av1_convolve_sr(const uint8_t* src, uint32_t src_stride, uint8_t* dst, uint32_t dst_stride, const svthip_convolve_desc* desc,

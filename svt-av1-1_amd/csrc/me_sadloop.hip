@@ -31,6 +31,10 @@ __device__ __forceinline__ uint32_t lds_u32_at(const lds_u8* p)
     return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
 }
 
+// global loads at byte alignment (one global_load_dword / _dwordx4 each; this target needs no alignment for them)
+struct __attribute__((packed, aligned(1))) unaligned_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) unaligned_u32x4 { uint32_t v[4]; };
+
 }  // namespace
 
 __global__ void __launch_bounds__(256) sad_loop_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, const uint8_t* __restrict__ ref,
@@ -99,147 +103,187 @@ __global__ void __launch_bounds__(256) sad_loop_kernel(const uint8_t* __restrict
     }
 }
 
-__host__ __device__ inline int sad_loop_qsad_pitch(int w, int sw)
+// Packed-SAD path for block widths 4 / 8 / 16 / 32 / 64 (W4 = width / 4 dwords), round 3: a 256-thread WORKGROUP owns `gb` blocks.
+//   * a lane owns 4 * NQ consecutive positions of one search row: per source dword NQ v_qsad_pk_u16_u8 (positions 4 n .. 4 n + 3 on the
+//     window dword pair (j + n, j + n + 1)) -- 16 abs-diff per instruction.  NQ (2, 3 or 4) is the one that pads the search width least:
+//     the 33 columns of configs[0] take 36 positions with NQ = 3 (40 with the eight-position form of round 2);
+//   * the items (block, search row, position group) of all gb blocks are dealt out over the 256 lanes as one flat list, so the last
+//     round of 64 lanes is shared by the blocks instead of being paid per block: 5 blocks x 99 items = 495 of 512 lane slots
+//     (one block per wave: 165 of 192); gb is chosen on the host for the fewest empty slots within the LDS budget;
+//   * a lane's best key goes to its block's LDS word with one ds_min_u32 per item; key = sad << 12 | raster position, so the minimum is
+//     the first minimum in raster order, the reference's strict-'<' update (C_DEFAULT/EbComputeSAD_C.c:73-119).
+// The packed 16-bit sums are widened every 256 / width rows (a row adds at most width / 4 * 1020 per position).
+struct SadLoopPlan {
+    int nq, gb, pitch, slice_bytes;
+    size_t lds_bytes;
+};
+
+inline SadLoopPlan sad_loop_plan(int w, int h, int sw, int sh, int k)
 {
-    const int p = (8 * ((sw + 7) >> 3) + w + 4 + 7) & ~7;
-    return (p & 8) ? p : p + 8;
+    SadLoopPlan p{};
+    int best_cols = 1 << 30;
+    for (int nq = 4; nq >= 2; nq--) {  // ties go to the larger group: fewer LDS reads per v_qsad
+        const int cols = 4 * nq * ((sw + 4 * nq - 1) / (4 * nq));
+        if (cols < best_cols) best_cols = cols, p.nq = nq;
+    }
+    // a row holds every group's width / 4 + nq dwords (zero beyond the window); rows are 16-byte units (staged with ds_write_b128), an odd
+    // number of them so that neighbouring search rows start on different banks
+    int pitch = (best_cols + w + 15) & ~15;
+    if (!((pitch >> 4) & 1)) pitch += 16;
+    p.pitch = pitch;
+    const int wrows = (sh - 1) + (h - 1) * k + 1;
+    p.slice_bytes = ((h * w + 15) & ~15) + wrows * pitch;
+    const int ipb = ((sw + 4 * p.nq - 1) / (4 * p.nq)) * sh;
+    double best_util = 0.0;
+    p.gb = 0;
+    for (int g = 1; g <= 16; g++) {
+        if (64 + (size_t)g * p.slice_bytes > 40 * 1024 && g > 1) break;
+        const int rounds = (g * ipb + 255) / 256;
+        const double util = (double)(g * ipb) / (256.0 * rounds);
+        if (util > best_util + 0.02) best_util = util, p.gb = g;
+    }
+    p.lds_bytes = 64 + (size_t)p.gb * p.slice_bytes;
+    return p;
 }
 
-// Fast path for block widths 4 / 8 / 16 / 32 / 64 (W4 = width / 4 dwords): same slice layout and staging, but a lane owns EIGHT
-// consecutive positions of one search row and the window dwords of a block row live in registers: per source dword two
-// v_qsad_pk_u16_u8 (positions 0..3 on the dword pair (j, j + 1), 4..7 on (j + 1, j + 2)) -- 16 abs-diff per instruction instead of 4.
-// The packed 16-bit sums are widened every 256 / width rows (a row adds at most width / 4 * 1020 per position).
-template <int W4>
+template <int W4, int NQ>
 __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __restrict__ src, uint32_t src_stride, const uint8_t* __restrict__ ref,
                                                             uint32_t ref_stride, uint32_t ref_stride_raw,
                                                             const svthip_sad_loop_desc* __restrict__ desc, uint32_t n_blocks, int h, int sw, int sh,
-                                                            int slice_bytes, uint32_t* __restrict__ best_sad, int16_t* __restrict__ best_xy)
+                                                            int gb, int slice_bytes, int pitch, uint32_t* __restrict__ best_sad,
+                                                            int16_t* __restrict__ best_xy)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int w = 4 * W4;
-    constexpr int FL = 256 / w;  // rows between two widenings
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * 4 + wave;
-    if (b >= n_blocks) return;  // whole wave; no workgroup barrier below
-    lds_u8* blk = (lds_u8*)smem + wave * slice_bytes;
-    lds_u8* win = blk + ((h * w + 7) & ~7);  // 8-byte aligned for the paired reads
+    constexpr int w = 4 * W4, PPL = 4 * NQ, NW = W4 + NQ;  // NW window dwords per lane and block row
+    constexpr int FL = 256 / w;                            // rows between two widenings
+    const int tid = threadIdx.x;
+    const uint32_t b0 = blockIdx.x * (uint32_t)gb;
+    const int nb = (int)min((uint32_t)gb, n_blocks - b0);
+    lds_u32* lds_best = reinterpret_cast<lds_u32*>((lds_u8*)smem);  // [16]
+    lds_u8* slices = (lds_u8*)smem + 64;
     const int k = (int)(ref_stride / ref_stride_raw);
-    const int ng = (sw + 7) >> 3;                                      // 8-position groups per search row
+    const int ng = (sw + PPL - 1) / PPL;
     const int wrows = (sh - 1) + (h - 1) * k + 1, wcols = w + sw - 1;
-    // every group's W4 + 2 dwords (+ 1: they are read as 8-byte pairs) exist (zero beyond the window); rows are an ODD number of 8-byte
-    // units so that the ds_read_b64 of lanes on neighbouring search rows fall on different banks
-    const int pitch = sad_loop_qsad_pitch(w, sw);
-    const svthip_sad_loop_desc d = desc[b];
-#pragma unroll 2
-    for (int i = lane; i < h * W4; i += 64) {
-        const int y = i / W4, x = 4 * (i - y * W4);
-        const uintptr_t a = reinterpret_cast<uintptr_t>(src + d.src_offset + (size_t)y * src_stride + x);
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-        const uint32_t hi = (a & 3u) ? q[1] : 0u;  // never touches a dword that holds no block byte
-        reinterpret_cast<lds_u32*>(blk)[i] = __builtin_amdgcn_alignbyte(hi, q[0], (uint32_t)(a & 3u));
-    }
+    const int blk_bytes = (h * w + 15) & ~15;
+    if (tid < 16) lds_best[tid] = 0xffffffffu;
+    // ---- stage the gb source blocks and windows (global loads at byte alignment; nothing is read beyond the dword that holds the
+    //      window's last column) ----
     {
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(ref + d.ref_offset);
-        const int ndw = pitch >> 2;
-        const uint32_t inv = (1u << 20) / (uint32_t)ndw + 1u;  // i / ndw for i < 2^14 (a slice is at most 16 KB): the emulated division was
-                                                               // ~20 of the ~35 vector instructions of a staging pass (round 3)
-#pragma unroll 4
-        for (int i = lane; i < wrows * ndw; i += 64) {
-            const int r = (int)(((uint32_t)i * inv) >> 20), c = i - r * ndw;
-            const uintptr_t a = a0 + (size_t)r * ref_stride_raw + 4 * c;
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
-            reinterpret_cast<lds_u32*>(win)[i] = 4 * c < wcols + 3 ? __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3u)) : 0u;
+        const int qpr = pitch >> 4, ndw_valid = (wcols + 3) >> 2;
+        const uint32_t inv_qpr = (uint32_t)((0x100000000ull + (uint32_t)qpr - 1u) / (uint32_t)qpr);
+        for (int bi = 0; bi < nb; bi++) {
+            const svthip_sad_loop_desc d = desc[b0 + bi];
+            lds_u8* blk = slices + bi * slice_bytes;
+            for (int i = tid; i < h * W4; i += 256) {
+                const int y = i / W4, x = 4 * (i - y * W4);
+                reinterpret_cast<lds_u32*>(blk)[i] = reinterpret_cast<const unaligned_u32*>(src + d.src_offset + (size_t)y * src_stride + x)->v;
+            }
+            const uint8_t* base = ref + d.ref_offset;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+            lds_u32x4* wq = reinterpret_cast<lds_u32x4*>(blk + blk_bytes);
+            for (int i = tid; i < wrows * qpr; i += 256) {
+                const int r = qpr == 1 ? i : (int)__umulhi((uint32_t)i, inv_qpr), c4 = i - r * qpr;
+                const uint8_t* p = base + (size_t)r * ref_stride_raw + 16 * c4;
+                const int left = ndw_valid - 4 * c4;
+                uint32_t t[4] = {0u, 0u, 0u, 0u};
+                if (left >= 4) {
+                    const unaligned_u32x4 u = *reinterpret_cast<const unaligned_u32x4*>(p);
+                    t[0] = u.v[0]; t[1] = u.v[1]; t[2] = u.v[2]; t[3] = u.v[3];
+                } else if (left > 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++)
+                        if (q < left) t[q] = reinterpret_cast<const unaligned_u32*>(p + 4 * q)->v;
+                }
+                wq[i] = u32x4{t[0], t[1], t[2], t[3]};
+            }
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    uint32_t best = 0xffffffffu;
-    const int n_items = ng * sh;
-    const uint32_t inv_ng = (1u << 20) / (uint32_t)ng + 1u;  // it / ng for it < 4096 * 8
-    for (int it = lane; it < n_items; it += 64) {
-        const int ys = (int)(((uint32_t)it * inv_ng) >> 20), x0 = 8 * (it - ys * ng);
-        uint32_t sum[8];
+    const int ipb = ng * sh, total = nb * ipb;
+    const uint32_t inv_ipb = (uint32_t)((0x100000000ull + (uint32_t)ipb - 1u) / (uint32_t)ipb);
+    const uint32_t inv_ng = (uint32_t)((0x100000000ull + (uint32_t)ng - 1u) / (uint32_t)ng);
+    const int rstep = (k * pitch) >> 2;
+    for (int t = tid; t < total; t += 256) {
+        // t / ipb and it / ng by reciprocal (exact below 2^16; a divisor of 1 has no 32-bit reciprocal)
+        const int bi = ipb == 1 ? t : (int)__umulhi((uint32_t)t, inv_ipb), it = t - bi * ipb;
+        const int ys = ng == 1 ? it : (int)__umulhi((uint32_t)it, inv_ng), x0 = PPL * (it - ys * ng);
+        const lds_u8* blk = slices + bi * slice_bytes;
+        const lds_u32* sp = reinterpret_cast<const lds_u32*>(blk);
+        const lds_u32* wp = reinterpret_cast<const lds_u32*>(blk + blk_bytes + ys * pitch + x0);
+        uint32_t sum[PPL];
 #pragma unroll
-        for (int i = 0; i < 8; i++) sum[i] = 0;
-        const lds_u32* wp = reinterpret_cast<const lds_u32*>(win + ys * pitch + x0);
-        const int rstep = (k * pitch) >> 2;
+        for (int i = 0; i < PPL; i++) sum[i] = 0;
         for (int y0 = 0; y0 < h; y0 += FL) {
-            uint64_t a0 = 0, a1 = 0;
+            uint64_t acc[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; n++) acc[n] = 0;
             const int y1 = min(h, y0 + FL);
             for (int y = y0; y < y1; y++) {
-                const lds_u32* srow = reinterpret_cast<const lds_u32*>(blk) + y * W4;
+                const lds_u32* srow = sp + y * W4;
                 const lds_u32* rrow = wp + y * rstep;
-                uint32_t W[W4 + 3];
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+                uint32_t Wd[NW], S[W4];
 #pragma unroll
-                for (int j = 0; j < (W4 + 3) / 2; j++) {  // 8-byte aligned: x0 is a multiple of 8 and so is the pitch
-                    const u32x2 t = reinterpret_cast<const lds_u32x2*>(rrow)[j];
-                    W[2 * j] = t.x;
-                    W[2 * j + 1] = t.y;
-                }
+                for (int j = 0; j < NW; j++) Wd[j] = rrow[j];
 #pragma unroll
-                for (int j = 0; j < W4; j++) {
-                    const uint32_t sj = srow[j];
-                    a0 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)W[j + 1] << 32) | W[j], sj, a0);
-                    a1 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)W[j + 2] << 32) | W[j + 1], sj, a1);
-                }
+                for (int j = 0; j < W4; j++) S[j] = srow[j];
+#pragma unroll
+                for (int j = 0; j < W4; j++)
+#pragma unroll
+                    for (int n = 0; n < NQ; n++)
+                        acc[n] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)Wd[j + n + 1] << 32) | Wd[j + n], S[j], acc[n]);
             }
-            sum[0] += (uint32_t)a0 & 0xffffu;
-            sum[1] += ((uint32_t)a0) >> 16;
-            sum[2] += (uint32_t)(a0 >> 32) & 0xffffu;
-            sum[3] += (uint32_t)(a0 >> 48);
-            sum[4] += (uint32_t)a1 & 0xffffu;
-            sum[5] += ((uint32_t)a1) >> 16;
-            sum[6] += (uint32_t)(a1 >> 32) & 0xffffu;
-            sum[7] += (uint32_t)(a1 >> 48);
+#pragma unroll
+            for (int n = 0; n < NQ; n++) {
+                sum[4 * n + 0] += (uint32_t)acc[n] & 0xffffu;
+                sum[4 * n + 1] += ((uint32_t)acc[n]) >> 16;
+                sum[4 * n + 2] += (uint32_t)(acc[n] >> 32) & 0xffffu;
+                sum[4 * n + 3] += (uint32_t)(acc[n] >> 48);
+            }
         }
         const uint32_t p0 = (uint32_t)(ys * sw + x0);
+        uint32_t best = 0xffffffffu;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < PPL; i++) {
             const uint32_t key = (x0 + i < sw) ? ((sum[i] << 12) | (p0 + i)) : 0xffffffffu;
             best = key < best ? key : best;
         }
+        __hip_atomic_fetch_min(reinterpret_cast<uint32_t*>(smem) + bi, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)best, m);
-        best = o < best ? o : best;
-    }
-    if (lane == 0) {
+    __syncthreads();
+    if (tid < nb) {
+        const uint32_t best = lds_best[tid];
         const int p = (int)(best & 0xfffu);
-        best_sad[b] = best >> 12;
-        best_xy[2 * b] = (int16_t)(p % sw);
-        best_xy[2 * b + 1] = (int16_t)(p / sw);
+        best_sad[b0 + tid] = best >> 12;
+        best_xy[2 * (b0 + tid)] = (int16_t)(p % sw);
+        best_xy[2 * (b0 + tid) + 1] = (int16_t)(p / sw);
     }
 }
 
-size_t sad_loop_qsad_slice_bytes(int w, int h, int sw, int sh, int k)
-{
-    const int wrows = (sh - 1) + (h - 1) * k + 1, pitch = sad_loop_qsad_pitch(w, sw);
-    return ((((size_t)h * w + 7) & ~(size_t)7) + (size_t)wrows * pitch + 8 + 15) & ~(size_t)15;
-}
+size_t sad_loop_qsad_lds_bytes(int w, int h, int sw, int sh, int k) { return sad_loop_plan(w, h, sw, sh, k).lds_bytes; }
 
 hipError_t launch_sad_loop_qsad(const uint8_t* src, uint32_t src_stride, const uint8_t* ref, uint32_t ref_stride, uint32_t ref_stride_raw,
-                                const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, int slice_bytes,
-                                uint32_t* best_sad, int16_t* best_xy, hipStream_t s)
+                                const svthip_sad_loop_desc* desc, uint32_t n_blocks, int w, int h, int sw, int sh, uint32_t* best_sad,
+                                int16_t* best_xy, hipStream_t s)
 {
-    const dim3 grid((n_blocks + 3) / 4), block(256);
-    const size_t lds = (size_t)slice_bytes * 4;
-#define SVTHIP_SADLOOP_CASE(W4)                                                                                                             \
-    case 4 * W4:                                                                                                                            \
-        hipLaunchKernelGGL(sad_loop_qsad_kernel<W4>, grid, block, lds, s, src, src_stride, ref, ref_stride, ref_stride_raw, desc, n_blocks, h, sw, \
-                           sh, slice_bytes, best_sad, best_xy);                                                                            \
+    const SadLoopPlan p = sad_loop_plan(w, h, sw, sh, (int)(ref_stride / ref_stride_raw));
+    const dim3 grid((n_blocks + p.gb - 1) / p.gb), block(256);
+#define SVTHIP_SADLOOP_CASE(W4, NQ)                                                                                                         \
+    case 16 * W4 + NQ:                                                                                                                      \
+        hipLaunchKernelGGL((sad_loop_qsad_kernel<W4, NQ>), grid, block, p.lds_bytes, s, src, src_stride, ref, ref_stride, ref_stride_raw, desc, \
+                           n_blocks, h, sw, sh, p.gb, p.slice_bytes, p.pitch, best_sad, best_xy);                                          \
         break;
-    switch (w) {
-        SVTHIP_SADLOOP_CASE(1)
-        SVTHIP_SADLOOP_CASE(2)
-        SVTHIP_SADLOOP_CASE(4)
-        SVTHIP_SADLOOP_CASE(8)
-        SVTHIP_SADLOOP_CASE(16)
+#define SVTHIP_SADLOOP_W(W4) SVTHIP_SADLOOP_CASE(W4, 2) SVTHIP_SADLOOP_CASE(W4, 3) SVTHIP_SADLOOP_CASE(W4, 4)
+    switch (4 * w + p.nq) {
+        SVTHIP_SADLOOP_W(1)
+        SVTHIP_SADLOOP_W(2)
+        SVTHIP_SADLOOP_W(4)
+        SVTHIP_SADLOOP_W(8)
+        SVTHIP_SADLOOP_W(16)
     default: return hipErrorInvalidValue;
     }
+#undef SVTHIP_SADLOOP_W
 #undef SVTHIP_SADLOOP_CASE
     return hipGetLastError();
 }

@@ -806,12 +806,13 @@ int32_t svthip_sad_loop_batch_dev(svthip_ctx* ctx, const uint8_t* d_src, uint32_
     if (!d_src || !d_ref || !d_desc || !d_best_sad || !d_best_xy) return fail(SVTHIP_ERR_BAD_PARAMETER, "null pointer argument%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     if ((width == 4 || width == 8 || width == 16 || width == 32 || width == 64) && !ctx->opt[SVTHIP_OPT_SADLOOP_GENERIC]) {
-        // packed-SAD kernel (eight positions per lane); falls through to the generic one when its slightly wider window rows do not fit
-        const size_t qs = svthip::sad_loop_qsad_slice_bytes((int)width, (int)height, (int)search_area_width, (int)search_area_height,
-                                                            (int)(ref_stride / ref_stride_raw));
-        if (qs * 4 <= 64 * 1024) {
+        // packed-SAD kernel (8 / 12 / 16 positions per lane, several blocks per workgroup); falls through to the generic one when its
+        // slightly wider window rows do not fit
+        const size_t qs = svthip::sad_loop_qsad_lds_bytes((int)width, (int)height, (int)search_area_width, (int)search_area_height,
+                                                          (int)(ref_stride / ref_stride_raw));
+        if (qs <= 64 * 1024) {
             HIP_TRY(svthip::launch_sad_loop_qsad(d_src, src_stride, d_ref, ref_stride, ref_stride_raw, d_desc, n_blocks, (int)width, (int)height,
-                                                 (int)search_area_width, (int)search_area_height, (int)qs, d_best_sad, d_best_xy, s));
+                                                 (int)search_area_width, (int)search_area_height, d_best_sad, d_best_xy, s));
             return SVTHIP_OK;
         }
     }

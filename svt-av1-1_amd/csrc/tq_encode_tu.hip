@@ -18,6 +18,15 @@
 //                           dimensions, quantiser, distortion, eob (reductions across the TU's lanes) -> inverse row
 //                           network on the dequantised row -> LDS tile (same row, same lane)
 //   C  lane = (tu, column): inverse column network -> prediction + residual -> clip -> reconstruction
+// Square sizes (round 3): the planes are touched by ROWS.  Read by columns, every sample was its own byte load -- a wave instruction
+// that moves 64 bytes and costs the texture path as many tag look-ups as a 1 KB one; the counters of the column form showed 63 memory
+// instructions and ~1440 L1 accesses per 1024 pixels with the L1 / data-return units ~90 % busy (profiles/r03_pmcx_tq_before.txt) while the
+// vector unit idled a third of the time.  Now
+//   A0 lane = (tu, row): source and prediction row in one wide load each -> residual row -> LDS tile (rows)
+//   A  lane = (tu, column): column from the tile -> forward column network -> tile
+//   B  as above
+//   C  lane = (tu, column): inverse column network -> clamped residual -> tile
+//   D  lane = (tu, row): residual row from the tile + the prediction row kept in registers since A0 -> clip -> one wide store
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,6 +60,10 @@ __device__ __forceinline__ int group_max_i32(int v)
     return v;
 }
 
+// One row of a TU as N dwords at byte alignment (global_load_dword / x2 / x4; this target needs no alignment for them).
+template <int N>
+struct __attribute__((packed, aligned(1))) unaligned_row { uint32_t v[N]; };
+
 // PIX = uint8_t: 8-bit planes (bd 8, quantize_b_helper_c_II); PIX = uint16_t: 10-bit samples in 16-bit planes (bd 10,
 // highbd_quantize_b_helper_c, Av1InvTransformRecon)
 // DIST: the coefficient-domain distortion sums of mode decision's full loop are wanted (dist_out != NULL).  The encode pass does not ask
@@ -83,30 +96,46 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
     const Clamp cl_col = {-(1 << 15), (1 << 15) - 1};             // max(bd + 6, 16) = 16 bits for bd 8 and 10
     constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), pix_max = (1 << BD) - 1;
     const uint32_t groups = (n_tu + G - 1) / G;
-    // Square sizes (one round per pass, the same TU on a lane in all three passes): everything the group reads from memory is
-    // requested ONCE, up front -- the descriptor, then in one batch the source / prediction columns, the quantiser row and (sizes up to 16)
-    // the inverse-scan row -- and the prediction samples stay in registers (four per VGPR) for the reconstruction.  Before, every pass
-    // re-read the descriptor and then its own inputs: six dependent memory round trips per group, and with ~4.4 waves per SIMD the counters
-    // showed each wave issuing 15 % of its 42 k-cycle life (profiles/r03_pmc_traffic.json: SQ_WAVE_CYCLES / SQ_WAVES vs SQ_INSTS_VALU).
-    constexpr int PER = 4 / (int)sizeof(PIX), PBITS = 8 * (int)sizeof(PIX);  // prediction samples per kept VGPR
+    // Square sizes (one round per pass, the same TU on a lane in every pass): everything the group reads from memory is requested
+    // ONCE, up front -- the descriptor, then in one batch the source / prediction ROWS, the quantiser row and (sizes up to 16) the
+    // inverse-scan row -- and the prediction row stays in registers (packed as loaded) for the reconstruction.
+    constexpr int PER = 4 / (int)sizeof(PIX), PBITS = 8 * (int)sizeof(PIX);  // samples per dword
     constexpr bool HOIST = (W == H) && (sizeof(PIX) == 1 || W <= 32);
     constexpr bool HOIST_ISCAN = HOIST && W <= 16;
+    constexpr int ROWDW = HOIST ? W / PER : 1;
     for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
         svthip_tu_desc dh{};
         QParams QPh{};
-        uint32_t ppk[HOIST ? H / PER : 1];
+        uint32_t ppk[ROWDW];
         short4 isc[HOIST_ISCAN ? W / 4 : 1];
         if constexpr (HOIST) {
-            const uint32_t tu = grp * G + lane / W;
+            const int g = lane / W, i = lane % W;
+            const uint32_t tu = grp * G + g;
             if (tu < n_tu) {
                 dh = desc[tu];
                 QPh = load_qparams(qparams + (size_t)dh.qparam_index * 10, LOG_SCALE);
                 if constexpr (HOIST_ISCAN) {
-                    const int16_t* iscan = iscan_pool + dh.iscan_offset + (lane % H) * WIN;
+                    const int16_t* iscan = iscan_pool + dh.iscan_offset + i * WIN;
 #pragma unroll
                     for (int c = 0; c < W / 4; c++) isc[c] = *reinterpret_cast<const short4*>(iscan + 4 * c);
                 }
+                // ---- A0: residual of image row i into the tile (row H - 1 - i under the up-down flip of FLIPADST columns) ----
+                const int kc = kVtx[dh.tx_type & 15];
+                const unaligned_row<ROWDW> sv = *reinterpret_cast<const unaligned_row<ROWDW>*>(src + dh.src_offset + (size_t)i * dh.src_stride);
+                const unaligned_row<ROWDW> pv = *reinterpret_cast<const unaligned_row<ROWDW>*>(pred + dh.pred_offset + (size_t)i * dh.pred_stride);
+                int32_t* row = tile + g * (H * P) + (kc == 2 ? H - 1 - i : i) * P;
+#pragma unroll
+                for (int c = 0; c < W; c++) {
+                    const int32_t sc = (int32_t)((sv.v[c / PER] >> (PBITS * (c % PER))) & ((1u << PBITS) - 1u));
+                    const int32_t pc = (int32_t)((pv.v[c / PER] >> (PBITS * (c % PER))) & ((1u << PBITS) - 1u));
+                    row[c] = shift_val<SH0>(sc - pc);
+                }
+#pragma unroll
+                for (int c = 0; c < ROWDW; c++) ppk[c] = pv.v[c];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // ---- A: residual + forward column pass ----
 #pragma unroll 1
@@ -122,12 +151,16 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                 const PIX* p = pred + d.pred_offset + c;
                 const int ss = d.src_stride, ps = d.pred_stride;
                 int32_t x[H], y[H];
+                if constexpr (HOIST) {
+                    const int32_t* cin = tile + g * (H * P) + c;
 #pragma unroll
-                for (int r = 0; r < H; r++) {
-                    const int rr = (kc == 2 ? H - 1 - r : r);
-                    const int32_t pv = (int32_t)p[rr * ps];
-                    x[r] = shift_val<SH0>((int32_t)s[rr * ss] - pv);
-                    if constexpr (HOIST) ppk[r / PER] = (r % PER) ? (ppk[r / PER] | ((uint32_t)pv << (PBITS * (r % PER)))) : (uint32_t)pv;
+                    for (int r = 0; r < H; r++) x[r] = cin[r * P];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < H; r++) {
+                        const int rr = (kc == 2 ? H - 1 - r : r);
+                        x[r] = shift_val<SH0>((int32_t)s[rr * ss] - (int32_t)p[rr * ps]);
+                    }
                 }
                 txfm1d<H, BITC>(kc, x, y);
                 int32_t* col = tile + g * (H * P) + (kr == 2 ? W - 1 - c : c);
@@ -265,22 +298,52 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                 const PIX* p = pred + d.pred_offset + c;
                 PIX* out = recon + d.recon_offset + c;
                 const int ps = d.pred_stride, rs_ = d.recon_stride;
+                if constexpr (HOIST) {
+                    int32_t* cout_ = tile + g * (H * P) + c;  // image column c, image rows (every lane has read its input column by now)
 #pragma unroll
-                for (int r = 0; r < H; r++) {
-                    int32_t t = rs<4>((int64_t)y[r]);
-                    t = min(max(t, -res_max - 1), res_max);
-                    const int rr = flip_row<H>(r, kc);
-                    int32_t pv;
-                    if constexpr (HOIST) pv = (int32_t)((ppk[r / PER] >> (PBITS * (r % PER))) & ((1u << PBITS) - 1u));  // the sample pass A read for its row r
-                    else pv = (int32_t)p[rr * ps];
-                    const int32_t v = pv + t;
-                    out[rr * rs_] = (PIX)min(max(v, 0), pix_max);
+                    for (int r = 0; r < H; r++) {
+                        const int32_t t = rs<4>((int64_t)y[r]);
+                        cout_[flip_row<H>(r, kc) * P] = min(max(t, -res_max - 1), res_max);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < H; r++) {
+                        int32_t t = rs<4>((int64_t)y[r]);
+                        t = min(max(t, -res_max - 1), res_max);
+                        const int rr = flip_row<H>(r, kc);
+                        const int32_t v = (int32_t)p[rr * ps] + t;
+                        out[rr * rs_] = (PIX)min(max(v, 0), pix_max);
+                    }
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- D (square sizes): reconstruction by rows ----
+        if constexpr (HOIST) {
+            const int g = lane / W, i = lane % W;
+            const uint32_t tu = grp * G + g;
+            if (tu < n_tu) {
+                const int32_t* row = tile + g * (H * P) + i * P;
+                unaligned_row<ROWDW> o;
+#pragma unroll
+                for (int c = 0; c < ROWDW; c++) {
+                    uint32_t pk = 0;
+#pragma unroll
+                    for (int k = 0; k < PER; k++) {
+                        const int32_t pc = (int32_t)((ppk[c] >> (PBITS * k)) & ((1u << PBITS) - 1u));
+                        const int32_t v = min(max(pc + row[c * PER + k], 0), pix_max);
+                        pk |= (uint32_t)v << (PBITS * k);
+                    }
+                    o.v[c] = pk;
+                }
+                *reinterpret_cast<unaligned_row<ROWDW>*>(recon + dh.recon_offset + (size_t)i * dh.recon_stride) = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 }
 
