@@ -134,10 +134,11 @@ inline SadLoopPlan sad_loop_plan(int w, int h, int sw, int sh, int k)
     const int wrows = (sh - 1) + (h - 1) * k + 1;
     p.slice_bytes = ((h * w + 15) & ~15) + wrows * pitch;
     const int ipb = ((sw + 4 * p.nq - 1) / (4 * p.nq)) * sh;
-    double best_util = 0.0;
-    p.gb = 0;
-    for (int g = 1; g <= 16; g++) {
-        if (64 + (size_t)g * p.slice_bytes > 40 * 1024 && g > 1) break;
+    // blocks per workgroup: the fewest that fill the lane slots of the last round (within 2 %), inside 40 KB of LDS (four workgroups per CU)
+    p.gb = 1;
+    double best_util = (double)ipb / (256.0 * ((ipb + 255) / 256));
+    for (int g = 2; g <= 16; g++) {
+        if (64 + (size_t)g * p.slice_bytes > 40 * 1024) break;
         const int rounds = (g * ipb + 255) / 256;
         const double util = (double)(g * ipb) / (256.0 * rounds);
         if (util > best_util + 0.02) best_util = util, p.gb = g;

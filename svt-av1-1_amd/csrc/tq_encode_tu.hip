@@ -90,39 +90,128 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
     constexpr int LOG_SCALE = (W * H > 256) + (W * H > 1024);  // av1_get_tx_scale (EbTransforms.h:312-316)
     extern __shared__ int32_t lds_all[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t* tile = lds_all + wave * (G * H * P);
+    // QSTAGE (square sizes up to 32): the quantised coefficients leave through a per-wave LDS image [64 rows][W + 4] and are stored as
+    // contiguous 1 KB pieces per instruction.  Stored straight from the row lanes, every lane's 16 bytes were their own write request at the L2
+    // (64 per instruction, 256 per group of 1024 pixels), and the stamps showed the row pass -- the one that issues them -- taking half of a
+    // group's time with a 4x spread (profiles/r03_tq_stamps_16x16_before.txt): waves queueing at the vector-memory issue.
+    constexpr bool QSTAGE = (W == H) && W <= 32;
+    constexpr int QP_ = W + 4;                                  // staging row pitch in dwords: 16-byte rows at a stride that spreads the banks
+    constexpr int WAVE_LDS = G * H * P + (QSTAGE ? 64 * QP_ + 16 : 0);
+    int32_t* tile = lds_all + wave * WAVE_LDS;
+    int32_t* qst = tile + G * H * P;                            // [64][QP_] then coeff_offset of the group's TUs [16]
     constexpr int BD = sizeof(PIX) == 1 ? 8 : 10, HIGHBD = sizeof(PIX) == 1 ? 0 : 1;
     const Clamp cl_in = {-(1 << (BD + 7)), (1 << (BD + 7)) - 1};  // bd + 8 bits
     const Clamp cl_col = {-(1 << 15), (1 << 15) - 1};             // max(bd + 6, 16) = 16 bits for bd 8 and 10
     constexpr int32_t res_max = (1 << (7 + BD)) - 1 + (914 << (BD - 7)), pix_max = (1 << BD) - 1;
     const uint32_t groups = (n_tu + G - 1) / G;
-    // Square sizes (one round per pass, the same TU on a lane in every pass): everything the group reads from memory is requested
-    // ONCE, up front -- the descriptor, then in one batch the source / prediction ROWS, the quantiser row and (sizes up to 16) the
-    // inverse-scan row -- and the prediction row stays in registers (packed as loaded) for the reconstruction.
+    // Square sizes (one round per pass, the same TU on a lane in every pass): everything a group reads from memory is requested
+    // AHEAD of the group, and the prediction row stays in registers (packed as loaded) for the reconstruction.  A wave walks its groups with
+    // a two-step prefetch: the descriptor of the next group is requested at the top of the current one, the next group's source /
+    // prediction rows, quantiser row and (sizes up to 16) inverse-scan row after the current group's column pass.  With one group per wave
+    // and ~3.4 waves per SIMD the counters showed a wave issuing a quarter of its 27 k-cycle life -- descriptor, then rows, then the
+    // stores, three exposed round trips -- and the vector unit busy 0.71 (profiles/r03_pmcx_tq_rows.txt).
     constexpr int PER = 4 / (int)sizeof(PIX), PBITS = 8 * (int)sizeof(PIX);  // samples per dword
     constexpr bool HOIST = (W == H) && (sizeof(PIX) == 1 || W <= 32);
     constexpr bool HOIST_ISCAN = HOIST && W <= 16;
     constexpr int ROWDW = HOIST ? W / PER : 1;
-    for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gridDim.x * 4) {
+    constexpr bool PIPE = HOIST && W <= 32;  // 64x64 has no registers to spare for a second set of rows: it fetches at the top of each group
+    const uint32_t gstride = gridDim.x * 4;
+    const int hg = lane / W, hi = lane % W;  // square sizes: the lane's TU of the group and its row (A0, B, D) / column (A, C)
+    svthip_tu_desc d_nx{};                   // next group: descriptor ...
+    unaligned_row<ROWDW> sv_nx{}, pv_nx{};   // ... source and prediction row,
+    unaligned_row<5> qp_nx{};                // ... the ten int16 quantiser parameters,
+    short4 isc_nx[HOIST_ISCAN ? W / 4 : 1];  // ... inverse-scan row
+    auto fetch_rows = [&](const svthip_tu_desc& d) {
+        sv_nx = *reinterpret_cast<const unaligned_row<ROWDW>*>(src + d.src_offset + (size_t)hi * d.src_stride);
+        pv_nx = *reinterpret_cast<const unaligned_row<ROWDW>*>(pred + d.pred_offset + (size_t)hi * d.pred_stride);
+        qp_nx = *reinterpret_cast<const unaligned_row<5>*>(qparams + (size_t)d.qparam_index * 10);
+        if constexpr (HOIST_ISCAN) {
+            const int16_t* iscan = iscan_pool + d.iscan_offset + hi * WIN;
+#pragma unroll
+            for (int c = 0; c < W / 4; c++) isc_nx[c] = *reinterpret_cast<const short4*>(iscan + 4 * c);
+        }
+    };
+    // (the prefetches are unconditional, from a clamped TU index: a load under a condition puts its result into the loop-carried registers
+    //  through copies right behind the load, i.e. waits for it on the spot)
+    // The next descriptor is loaded as two raw 16-byte halves into registers that are NOT loop-carried and is unpacked behind an empty asm
+    // after the column pass: unpacked where it is loaded, the compiler copies its fields into the loop-carried registers right behind the
+    // load (s_waitcnt vmcnt + v_mov), one exposed memory round trip per group.
+    struct RawDesc { unaligned_row<4> a, b; };
+    auto load_desc_raw = [&](uint32_t tu) {
+        const unaligned_row<4>* p = reinterpret_cast<const unaligned_row<4>*>(desc + tu);
+        RawDesc r;
+        r.a = p[0];
+        r.b = p[1];
+        return r;
+    };
+    auto unpack_desc = [](const RawDesc& r) {
+        svthip_tu_desc d;
+        d.src_offset = r.a.v[0];
+        d.pred_offset = r.a.v[1];
+        d.recon_offset = r.a.v[2];
+        d.coeff_offset = r.a.v[3];
+        d.iscan_offset = r.b.v[0];
+        d.src_stride = (uint16_t)r.b.v[1];
+        d.pred_stride = (uint16_t)(r.b.v[1] >> 16);
+        d.recon_stride = (uint16_t)r.b.v[2];
+        d.qparam_index = (uint16_t)(r.b.v[2] >> 16);
+        d.tx_type = (uint8_t)r.b.v[3];
+        return d;
+    };
+    static_assert(sizeof(svthip_tu_desc) == 32, "svthip_tu_desc is read as two 16-byte halves");
+    if constexpr (PIPE) {
+        if (n_tu == 0) return;
+        const uint32_t grp0 = blockIdx.x * 4 + wave;
+        d_nx = unpack_desc(load_desc_raw(min(grp0 * G + hg, n_tu - 1)));
+        fetch_rows(d_nx);
+    }
+#ifdef SVTHIP_TQ_STAMPS  // debug build (tools/tq_stamps_probe.py): phase time stamps of every group's lane 0 into coeff_out (as uint64 [group][8])
+    uint64_t stamp[8];
+#define SVTHIP_STAMP(k) stamp[k] = __builtin_readcyclecounter()
+#else
+#define SVTHIP_STAMP(k)
+#endif
+    unaligned_row<ROWDW> o_dfr{};  // the previous group's reconstructed row, not stored yet
+    PIX* o_ptr = nullptr;
+    for (uint32_t grp = blockIdx.x * 4 + wave; grp < groups; grp += gstride) {
+        SVTHIP_STAMP(0);
         svthip_tu_desc dh{};
+        RawDesc rd_nx{};
         QParams QPh{};
         uint32_t ppk[ROWDW];
         short4 isc[HOIST_ISCAN ? W / 4 : 1];
         if constexpr (HOIST) {
-            const int g = lane / W, i = lane % W;
+            const int g = hg, i = hi;
             const uint32_t tu = grp * G + g;
-            if (tu < n_tu) {
-                dh = desc[tu];
-                QPh = load_qparams(qparams + (size_t)dh.qparam_index * 10, LOG_SCALE);
-                if constexpr (HOIST_ISCAN) {
-                    const int16_t* iscan = iscan_pool + dh.iscan_offset + i * WIN;
+            if constexpr (!PIPE) {
+                if (tu < n_tu) {
+                    d_nx = desc[tu];
+                    fetch_rows(d_nx);
+                }
+            }
+            // this group's operands were requested one group ago; the next group's descriptor goes out now
+            dh = d_nx;
+            const unaligned_row<ROWDW> sv = sv_nx, pv = pv_nx;
+            const unaligned_row<5> qpr = qp_nx;
 #pragma unroll
-                    for (int c = 0; c < W / 4; c++) isc[c] = *reinterpret_cast<const short4*>(iscan + 4 * c);
+            for (int c = 0; c < (HOIST_ISCAN ? W / 4 : 1); c++) isc[c] = isc_nx[c];
+            if constexpr (PIPE) {
+                rd_nx = load_desc_raw(min((grp + gstride) * G + g, n_tu - 1));
+                if (o_ptr) *reinterpret_cast<unaligned_row<ROWDW>*>(o_ptr) = o_dfr;
+                o_ptr = nullptr;
+            }
+            if (tu < n_tu) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {  // {zbin, round, quant, quant_shift, dequant} x {DC, AC}, as load_qparams
+                    const auto half = [&](int j) { return (int32_t)(int16_t)(qpr.v[j >> 1] >> (16 * (j & 1))); };
+                    QPh.zb[k] = rpot(half(k), LOG_SCALE);
+                    QPh.rnd[k] = rpot(half(2 + k), LOG_SCALE);
+                    QPh.quant[k] = half(4 + k);
+                    QPh.shift[k] = half(6 + k);
+                    QPh.deq[k] = half(8 + k);
                 }
                 // ---- A0: residual of image row i into the tile (row H - 1 - i under the up-down flip of FLIPADST columns) ----
                 const int kc = kVtx[dh.tx_type & 15];
-                const unaligned_row<ROWDW> sv = *reinterpret_cast<const unaligned_row<ROWDW>*>(src + dh.src_offset + (size_t)i * dh.src_stride);
-                const unaligned_row<ROWDW> pv = *reinterpret_cast<const unaligned_row<ROWDW>*>(pred + dh.pred_offset + (size_t)i * dh.pred_stride);
                 int32_t* row = tile + g * (H * P) + (kc == 2 ? H - 1 - i : i) * P;
 #pragma unroll
                 for (int c = 0; c < W; c++) {
@@ -137,6 +226,7 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        SVTHIP_STAMP(1);
         // ---- A: residual + forward column pass ----
 #pragma unroll 1
         for (int round = 0; round < ROUNDS_COL; round++) {
@@ -171,6 +261,14 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SVTHIP_STAMP(2);
+        if constexpr (PIPE) {
+            asm volatile("" : "+v"(rd_nx.a.v[0]), "+v"(rd_nx.a.v[1]), "+v"(rd_nx.a.v[2]), "+v"(rd_nx.a.v[3]), "+v"(rd_nx.b.v[0]), "+v"(rd_nx.b.v[1]),
+                         "+v"(rd_nx.b.v[2]), "+v"(rd_nx.b.v[3]));
+            d_nx = unpack_desc(rd_nx);
+            fetch_rows(d_nx);  // in flight during the row, inverse and reconstruction passes of this group
+        }
+        SVTHIP_STAMP(3);
         // ---- B: forward row pass, quantiser, inverse row pass ----
 #pragma unroll 1
         for (int round = 0; round < ROUNDS_ROW; round++) {
@@ -236,8 +334,11 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                                 dist_pred = mad64(y[c + k], y[c + k], dist_pred);
                             }
                         }
-                        *reinterpret_cast<int4*>(qcoeff_out + base + c) = make_int4(qv[0], qv[1], qv[2], qv[3]);
+                        if constexpr (QSTAGE) *reinterpret_cast<int4*>(qst + lane * QP_ + c) = make_int4(qv[0], qv[1], qv[2], qv[3]);
+                        else *reinterpret_cast<int4*>(qcoeff_out + base + c) = make_int4(qv[0], qv[1], qv[2], qv[3]);
+#ifndef SVTHIP_TQ_STAMPS
                         if (coeff_out) *reinterpret_cast<int4*>(coeff_out + base + c) = make_int4(y[c], y[c + 1], y[c + 2], y[c + 3]);
+#endif
                         if (dqcoeff_out)
                             *reinterpret_cast<int4*>(dqcoeff_out + base + c) = make_int4(dq[c], dq[c + 1], dq[c + 2], dq[c + 3]);
                     }
@@ -266,6 +367,9 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                 dist_pred = (int64_t)group_sum_u64<H>((uint64_t)dist_pred);
             }
             if constexpr (W > 32 || H > 32) energy = (int64_t)group_sum_u64<H>((uint64_t)energy);
+            if constexpr (QSTAGE) {
+                if (r == 0) qst[64 * QP_ + g] = (int32_t)(active ? dh.coeff_offset : 0xffffffffu);  // offsets are multiples of 4: all-ones marks a missing TU
+            }
             if (active && r == 0) {
                 eob_out[tu] = (uint16_t)last;
                 if (energy_out) energy_out[tu] = (uint64_t)energy;
@@ -278,6 +382,17 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (QSTAGE) {
+            // quad q = k * 64 + lane of the group's 64 x W coefficients: row R = q / (W / 4) of the image, TU R / H, row R % H of that TU
+#pragma unroll
+            for (int k = 0; k < W / 4; k++) {
+                const int q = k * 64 + lane, R = q / (W / 4), cq = q % (W / 4);
+                const int4 v = *reinterpret_cast<const int4*>(qst + R * QP_ + 4 * cq);
+                const uint32_t off = (uint32_t)qst[64 * QP_ + R / H];
+                if (off != 0xffffffffu) *reinterpret_cast<int4*>(qcoeff_out + off + (R % H) * W + 4 * cq) = v;
+            }
+        }
+        SVTHIP_STAMP(4);
         // ---- C: inverse column pass + reconstruction ----
 #pragma unroll 1
         for (int round = 0; round < ROUNDS_COL; round++) {
@@ -320,6 +435,7 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SVTHIP_STAMP(5);
         // ---- D (square sizes): reconstruction by rows ----
         if constexpr (HOIST) {
             const int g = lane / W, i = lane % W;
@@ -338,12 +454,29 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                     }
                     o.v[c] = pk;
                 }
-                *reinterpret_cast<unaligned_row<ROWDW>*>(recon + dh.recon_offset + (size_t)i * dh.recon_stride) = o;
+                PIX* optr = recon + dh.recon_offset + (size_t)i * dh.recon_stride;
+                if constexpr (PIPE) {  // stored at the top of the wave's next group: the loop-carried prefetch makes the end of a group wait for
+                    o_dfr = o;         // everything in flight, and a store issued here would be waited for at once
+                    o_ptr = optr;
+                } else {
+                    *reinterpret_cast<unaligned_row<ROWDW>*>(optr) = o;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#ifdef SVTHIP_TQ_STAMPS
+        SVTHIP_STAMP(6);
+        if (lane == 0 && coeff_out) {
+            stamp[7] = ((uint64_t)blockIdx.x << 8) | (uint64_t)wave;
+#pragma unroll
+            for (int k = 0; k < 8; k++) reinterpret_cast<uint64_t*>(coeff_out)[(size_t)grp * 8 + k] = stamp[k];
+        }
+#endif
+    }
+    if constexpr (PIPE) {
+        if (o_ptr) *reinterpret_cast<unaligned_row<ROWDW>*>(o_ptr) = o_dfr;
     }
 }
 
@@ -353,10 +486,24 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
                       uint64_t* energy, uint64_t* dist, hipStream_t s)
 {
     constexpr int W = 1 << WL, H = 1 << HL, MIND = W < H ? W : H, G = 64 / MIND;
-    constexpr size_t lds = (size_t)4 * G * H * (W + 1) * sizeof(int32_t);
+    constexpr bool QSTAGE = (W == H) && W <= 32;  // as in the kernel
+    constexpr size_t lds = (size_t)4 * (G * H * (W + 1) + (QSTAGE ? 64 * (W + 4) + 16 : 0)) * sizeof(int32_t);
     const uint32_t groups = (n_tu + G - 1) / G;
     uint32_t blocks = (groups + 3) / 4;
     if (blocks > 256u * 64u) blocks = 256u * 64u;
+    constexpr bool PIPELINED = (W == H) && W <= 32;  // the kernel's PIPE: waves walk several groups, prefetching
+    if constexpr (PIPELINED) {
+        // as many workgroups as the chip holds at once (all of one kernel variant's launches run on one GPU model)
+        static const uint32_t resident = [] {
+            int dev = 0, cus = 256, per_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, false>), 256, lds) !=
+                    hipSuccess || per_cu < 1)
+                per_cu = 2;
+            return (uint32_t)(cus * per_cu);
+        }();
+        if (blocks > resident) blocks = resident;
+    }
     if (lds > 64 * 1024) {
         static hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -90,8 +90,21 @@ __device__ __forceinline__ void rot_q(int32_t* p, int al)
     p[0] = hb<BIT>(-COS(64 - al), x, COS(al), y);
     p[1] = hb<BIT>(COS(al), x, COS(64 - al), y);
 }
-__device__ constexpr int8_t kVtx[16] = {0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3};  // vtx_tab (EbTransforms.h:88)
-__device__ constexpr int8_t kHtx[16] = {0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2};  // htx_tab (:93)
+// 1-D kernel class of a 2-D transform type (0 DCT, 1 ADST, 2 FLIPADST, 3 identity), two bits per type in one 32-bit literal.  As
+// __device__ arrays these were tables in memory: one dependent global_load_ubyte per pass and TU group, and the s_waitcnt vmcnt(0) in
+// front of its use also waited for every prefetch in flight.
+struct TxClassTable {
+    uint32_t bits;
+    __host__ __device__ constexpr int operator[](int tx_type) const { return (int)((bits >> (2 * tx_type)) & 3u); }
+};
+constexpr uint32_t pack_tx_classes(const int (&v)[16])
+{
+    uint32_t w = 0;
+    for (int i = 0; i < 16; i++) w |= (uint32_t)v[i] << (2 * i);
+    return w;
+}
+constexpr TxClassTable kVtx = {pack_tx_classes({0, 1, 0, 1, 2, 0, 2, 1, 2, 3, 0, 3, 1, 3, 2, 3})};  // vtx_tab (EbTransforms.h:88)
+constexpr TxClassTable kHtx = {pack_tx_classes({0, 0, 1, 1, 0, 2, 2, 2, 1, 3, 3, 0, 3, 1, 3, 2})};  // htx_tab (:93)
 
 // Destination row of output r under the up-down flip of FLIPADST columns (only sizes up to 16 have ADST).  The row index is
 // made opaque: written as a select between y[H-1-r] and y[r] (or between two addresses) the compiler turns the flip into a
