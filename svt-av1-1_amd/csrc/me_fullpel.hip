@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(256, SVTHIP_FULLPEL_MIN_WAVES) fullpel85_kerne
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t sb = xcd_item(blockIdx.x, n_sb);  // raster neighbours share an XCD's L2 (me_kernels.h)
     if (sb >= n_sb) return;
-    fullpel85_sb(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
+    // wave-uniform choice of the search-loop form (me_fullpel_impl.h): windows clipped at the picture's left / right edge take the general one
+    if ((desc[6 * sb + 4] & 15) == 0) fullpel85_sb<true>(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
+    else fullpel85_sb<false>(src_plane, src_stride, ref_plane, ref_stride, desc + 6 * sb, sb, out_sad, out_mv, smem);
 }
 
 }  // namespace svthip

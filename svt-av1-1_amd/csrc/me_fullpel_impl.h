@@ -31,6 +31,13 @@ __device__ __forceinline__ uint32_t track4(uint32_t best, uint64_t acc, const ui
     return best;
 }
 
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -61,6 +68,14 @@ __device__ __forceinline__ uint32_t mv_word(int x, int y)
 // d: the superblock's descriptor (6 int32: src_offset, ref_offset, x/y search origin, search width/height), any address space;
 // smem: SVTHIP_FULLPEL_LDS_FIXED + (sh + 63) * SVTHIP_FULLPEL_LDS_PITCH bytes of workgroup LDS, 16-byte aligned.
 // Results go to out_sad / out_mv [85 * sbi ...].  Must be called by all 256 threads.
+// CLS (search width a multiple of 16, the usual case; wave-uniform): the 8x8 PUs -- 256 of the 336 (PU, position) candidates of an item --
+// are tracked per position CLASS.  The four quads of a lane's 16 positions are first reduced with packed 16-bit minima (slot c of the
+// result = min over q of the SAD at position 4 q + c), then ONE quad of keys (sad << 16 | idx0 + c) goes into the running minimum: 12
+// instructions per PU and item instead of 24.  The winner of a PU then names its item (idx0) and its SAD but not the position inside the
+// item: items are disjoint runs of 16 raster positions, so the first minimum in raster order lies in the first item that attains the
+// minimum -- which is what the key order picks -- and after the search four lanes per PU recompute that item's 16 SADs (8 v_qsad per lane,
+// once per superblock) and take the first position whose SAD equals the minimum: the reference's strict-'<' rule again.
+template <bool CLS>
 __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_plane, uint32_t src_stride,
                                              const uint8_t* __restrict__ ref_plane, uint32_t ref_stride, const int32_t* d, uint32_t sbi,
                                              uint32_t* __restrict__ out_sad, uint32_t* __restrict__ out_mv, uint8_t* smem)
@@ -121,6 +136,18 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
     // source pixels of this wave's quadrant (wave-uniform -> scalar loads)
     const uint32_t* src4 = reinterpret_cast<const uint32_t*>(src_plane + src_off + (size_t)(32 * Qy) * src_stride + 32 * Qx);
     const int sstride4 = src_stride >> 2;
+
+    // CLS: the source rows of the 8x8 PU this lane will resolve (lane = 4 * PU + quad), requested now, used after the search
+    uint32_t rsv[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if constexpr (CLS) {
+        const int p = lane >> 2, zz = p >> 2, k = p & 3, px = 16 * (zz & 1) + 8 * (k & 1), py = 16 * (zz >> 1) + 8 * (k >> 1);
+        const uint32_t* sp = src4 + (size_t)py * sstride4 + (px >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            rsv[r][0] = sp[(size_t)(2 * r) * sstride4];
+            rsv[r][1] = sp[(size_t)(2 * r) * sstride4 + 1];
+        }
+    }
 
     uint32_t best8[16], best16[4], best32 = 0xffffffffu;
 #pragma unroll
@@ -209,9 +236,17 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
 
             // 8x8 PUs of this 16x16
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < 4; k++) {
+                if constexpr (CLS) {
+                    const uint32_t mlo = pk_min_u16(pk_min_u16((uint32_t)acc[k][0], (uint32_t)acc[k][1]), pk_min_u16((uint32_t)acc[k][2], (uint32_t)acc[k][3]));
+                    const uint32_t mhi = pk_min_u16(pk_min_u16((uint32_t)(acc[k][0] >> 32), (uint32_t)(acc[k][1] >> 32)),
+                                                    pk_min_u16((uint32_t)(acc[k][2] >> 32), (uint32_t)(acc[k][3] >> 32)));
+                    best8[4 * zz + k] = track4(best8[4 * zz + k], pack64(mlo, mhi), &idx[0], himask);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) best8[4 * zz + k] = track4(best8[4 * zz + k], acc[k][q], &idx[4 * q], himask);
+                    for (int q = 0; q < 4; q++) best8[4 * zz + k] = track4(best8[4 * zz + k], acc[k][q], &idx[4 * q], himask);
+                }
+            }
 
             // 16x16 = sum of the four 8x8 (packed u16, no carry between halves: <= 4*(8160+8200))
 #pragma unroll
@@ -287,7 +322,34 @@ __device__ __forceinline__ void fullpel85_sb(const uint8_t* __restrict__ src_pla
     const uint32_t g16 = wave_min_scatter<8, 5>(top, lane);
     const unsigned long long k64 = wave_min_u64(((unsigned long long)best64_raw << 32) | best64_idx);
 
-    if (lane < 21) {
+    if constexpr (CLS) {
+        // resolve the 8x8 winners: lane = 4 * PU + quad recomputes the SADs of positions 4 quad .. 4 quad + 3 of the winning item
+        const int p = lane >> 2, q = lane & 3;
+        const uint32_t key = (uint32_t)__shfl((int)g8, p);
+        const uint32_t s = key >> 16, id = key & 0xffffu;  // id = y * 128 + 16 * xg + class
+        const int y = (int)(id >> 7), xb = (int)(id & 0x70u);
+        const int zz = p >> 2, k = p & 3, px = 16 * (zz & 1) + 8 * (k & 1), py = 16 * (zz >> 1) + 8 * (k >> 1);
+        const uint8_t* wp = win + (y + 32 * Qy + py) * kPitch + xb + 4 * q + 32 * Qx + px;
+        uint64_t a = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(wp + 2 * r * kPitch);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            a = __builtin_amdgcn_qsad_pk_u16_u8(pack64(w0, w1), rsv[r][0], a);
+            a = __builtin_amdgcn_qsad_pk_u16_u8(pack64(w1, w2), rsv[r][1], a);
+        }
+        const uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+        uint32_t first = (lo & 0xffffu) == s ? 0u : (lo >> 16) == s ? 1u : (hi & 0xffffu) == s ? 2u : (hi >> 16) == s ? 3u : 64u;
+        first += 4u * (uint32_t)q;
+        first = min(first, (uint32_t)__shfl_xor((int)first, 1));
+        first = min(first, (uint32_t)__shfl_xor((int)first, 2));
+        if (q == 0) {
+            const int pu = 21 + 16 * Q + p;
+            osad[pu] = 2u * s;
+            omv[pu] = mv_word(xo + xb + (int)first, yo + y);
+        }
+    }
+    if (lane < 21 && !(CLS && lane < 16)) {
         const uint32_t key = lane < 16 ? g8 : g16;
         const int pu = lane < 16 ? 21 + 16 * Q + lane : lane < 20 ? 5 + 4 * Q + (lane - 16) : 1 + Q;
         const uint32_t raw = lane == 20 ? key >> 14 : key >> 16, id = key & 0x3fffu;

@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
 #pragma unroll
             for (int n = 0; n < NQ; n++) acc[n] = 0;
             const int y1 = min(h, y0 + FL);
+#pragma unroll 2
             for (int y = y0; y < y1; y++) {
                 const lds_u32* srow = sp + y * W4;
                 const lds_u32* rrow = wp + y * rstep;
