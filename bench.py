@@ -623,7 +623,7 @@ def leg_sad_loop(ctx, torch, svtav1_hip, timer, dev):
     return {"blocks": n, "ms": round(ms, 4), "blocks_per_s": round(n / ms * 1e3, 0), "absdiff_per_s": round(absdiff / ms * 1e3, 0),
             "frac_sad_ceiling": round(absdiff / ms * 1e3 / VALU_PEAK_ABSDIFF_PER_S, 4),
             **counters(pmc_entry("sad_loop_qsad_kernel"), ms, n * (256 + 48 * 48 + 8)),
-            "workload": "16x16 blocks, 33x33 positions (+-16), 856x480 8-bit, 12 pictures per launch, SadLoopKernel semantics (packed-SAD kernel: 8 positions per lane, v_qsad_pk_u16_u8)"}
+            "workload": "16x16 blocks, 33x33 positions (+-16), 856x480 8-bit, 12 pictures per launch, SadLoopKernel semantics (packed-SAD kernel: 12 positions per lane, five blocks per workgroup, v_qsad_pk_u16_u8)"}
 
 
 def leg_4k(ctx, torch, svtav1_hip, timer, dev, rng):

@@ -113,6 +113,9 @@ __global__ void __launch_bounds__(256) sad_loop_kernel(const uint8_t* __restrict
 //   * a lane's best key goes to its block's LDS word with one ds_min_u32 per item; key = sad << 12 | raster position, so the minimum is
 //     the first minimum in raster order, the reference's strict-'<' update (C_DEFAULT/EbComputeSAD_C.c:73-119).
 // The packed 16-bit sums are widened every 256 / width rows (a row adds at most width / 4 * 1020 per position).
+// LDS image of a block's window: rows of `pitch` bytes; a group starts 4 * NQ bytes after its neighbour and is read with ds_read_b64 (NQ = 2) /
+// ds_read_b128 (NQ = 4) at 256 B/clk, or ds_read2_b32 (NQ = 3: a 12-position group can start on an odd dword).  A chunk-major "cell" image
+// that gave the 12-position groups ds_read_b128 too halved the LDS cycles (counters) but cost more staging instructions than it saved: dropped.
 struct SadLoopPlan {
     int nq, gb, pitch, slice_bytes;
     size_t lds_bytes;
@@ -131,19 +134,20 @@ inline SadLoopPlan sad_loop_plan(int w, int h, int sw, int sh, int k)
     int pitch = (best_cols + w + 15) & ~15;
     if (!((pitch >> 4) & 1)) pitch += 16;
     p.pitch = pitch;
-    const int wrows = (sh - 1) + (h - 1) * k + 1;
-    p.slice_bytes = ((h * w + 15) & ~15) + wrows * pitch;
-    const int ipb = ((sw + 4 * p.nq - 1) / (4 * p.nq)) * sh;
+    const int wrows = (sh - 1) + (h - 1) * k + 1, ng = (sw + 4 * p.nq - 1) / (4 * p.nq);
+    const int blk_bytes = (h * w + 15) & ~15;
+    p.slice_bytes = blk_bytes + wrows * pitch;
+    const int ipb = ng * sh;
     // blocks per workgroup: the fewest that fill the lane slots of the last round (within 2 %), inside 40 KB of LDS (four workgroups per CU)
     p.gb = 1;
     double best_util = (double)ipb / (256.0 * ((ipb + 255) / 256));
     for (int g = 2; g <= 16; g++) {
-        if (64 + (size_t)g * p.slice_bytes > 40 * 1024) break;
+        if (192 + (size_t)g * p.slice_bytes > 40 * 1024) break;
         const int rounds = (g * ipb + 255) / 256;
         const double util = (double)(g * ipb) / (256.0 * rounds);
         if (util > best_util + 0.02) best_util = util, p.gb = g;
     }
-    p.lds_bytes = 64 + (size_t)p.gb * p.slice_bytes;
+    p.lds_bytes = 192 + (size_t)p.gb * p.slice_bytes;
     return p;
 }
 
@@ -156,48 +160,61 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int w = 4 * W4, PPL = 4 * NQ, NW = W4 + NQ;  // NW window dwords per lane and block row
+    constexpr int CH = (NW + 3) / 4;                       // 16-byte chunks a lane reads per window row (NQ = 4)
     constexpr int FL = 256 / w;                            // rows between two widenings
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     const int tid = threadIdx.x;
     const uint32_t b0 = blockIdx.x * (uint32_t)gb;
     const int nb = (int)min((uint32_t)gb, n_blocks - b0);
     lds_u32* lds_best = reinterpret_cast<lds_u32*>((lds_u8*)smem);  // [16]
-    lds_u8* slices = (lds_u8*)smem + 64;
+    lds_u8* slices = (lds_u8*)smem + 192;
     const int k = (int)(ref_stride / ref_stride_raw);
     const int ng = (sw + PPL - 1) / PPL;
     const int wrows = (sh - 1) + (h - 1) * k + 1, wcols = w + sw - 1;
     const int blk_bytes = (h * w + 15) & ~15;
+    // header: best keys [16], then the descriptors of the workgroup's blocks [16]
+    lds_u32* lds_desc = lds_best + 16;
     if (tid < 16) lds_best[tid] = 0xffffffffu;
-    // ---- stage the gb source blocks and windows (global loads at byte alignment; nothing is read beyond the dword that holds the
-    //      window's last column) ----
+    if (tid < nb) {
+        const svthip_sad_loop_desc d = desc[b0 + tid];
+        lds_desc[2 * tid] = d.src_offset;
+        lds_desc[2 * tid + 1] = d.ref_offset;
+    }
+    __syncthreads();
+    // ---- stage the nb source blocks and windows (global loads at byte alignment; nothing is read beyond the dword that holds the window's
+    //      last column).  A thread stages whole ROWS: the address arithmetic (two reciprocal divisions, a 64-bit row address) is paid once per
+    //      row instead of once per 16-byte unit -- per unit it made staging 40 % of the kernel's vector instructions. ----
     {
-        const int qpr = pitch >> 4, ndw_valid = (wcols + 3) >> 2;
-        const uint32_t inv_qpr = (uint32_t)((0x100000000ull + (uint32_t)qpr - 1u) / (uint32_t)qpr);
-        for (int bi = 0; bi < nb; bi++) {
-            const svthip_sad_loop_desc d = desc[b0 + bi];
-            lds_u8* blk = slices + bi * slice_bytes;
-            for (int i = tid; i < h * W4; i += 256) {
-                const int y = i / W4, x = 4 * (i - y * W4);
-                reinterpret_cast<lds_u32*>(blk)[i] = reinterpret_cast<const unaligned_u32*>(src + d.src_offset + (size_t)y * src_stride + x)->v;
-            }
-            const uint8_t* base = ref + d.ref_offset;
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-            lds_u32x4* wq = reinterpret_cast<lds_u32x4*>(blk + blk_bytes);
-            for (int i = tid; i < wrows * qpr; i += 256) {
-                const int r = qpr == 1 ? i : (int)__umulhi((uint32_t)i, inv_qpr), c4 = i - r * qpr;
-                const uint8_t* p = base + (size_t)r * ref_stride_raw + 16 * c4;
-                const int left = ndw_valid - 4 * c4;
+        const int ndw_valid = (wcols + 3) >> 2, qpr = pitch >> 4;
+        const uint32_t inv_wrows = (uint32_t)((0x100000000ull + (uint32_t)wrows - 1u) / (uint32_t)wrows);
+        for (int u = tid; u < nb * wrows; u += 256) {
+            const int bi = wrows == 1 ? u : (int)__umulhi((uint32_t)u, inv_wrows), r = u - bi * wrows;
+            const uint8_t* p = ref + lds_desc[2 * bi + 1] + (size_t)r * ref_stride_raw;
+            lds_u32x4* wq = reinterpret_cast<lds_u32x4*>(slices + bi * slice_bytes + blk_bytes + r * pitch);
+            for (int c = 0; c < qpr; c++) {
+                const int left = ndw_valid - 4 * c;
                 uint32_t t[4] = {0u, 0u, 0u, 0u};
                 if (left >= 4) {
-                    const unaligned_u32x4 u = *reinterpret_cast<const unaligned_u32x4*>(p);
-                    t[0] = u.v[0]; t[1] = u.v[1]; t[2] = u.v[2]; t[3] = u.v[3];
+                    const unaligned_u32x4 v = *reinterpret_cast<const unaligned_u32x4*>(p + 16 * c);
+                    t[0] = v.v[0]; t[1] = v.v[1]; t[2] = v.v[2]; t[3] = v.v[3];
                 } else if (left > 0) {
 #pragma unroll
                     for (int q = 0; q < 3; q++)
-                        if (q < left) t[q] = reinterpret_cast<const unaligned_u32*>(p + 4 * q)->v;
+                        if (q < left) t[q] = reinterpret_cast<const unaligned_u32*>(p + 16 * c + 4 * q)->v;
                 }
-                wq[i] = u32x4{t[0], t[1], t[2], t[3]};
+                wq[c] = u32x4{t[0], t[1], t[2], t[3]};
             }
+        }
+        const uint32_t inv_h = (uint32_t)((0x100000000ull + (uint32_t)h - 1u) / (uint32_t)h);
+        for (int u = tid; u < nb * h; u += 256) {
+            const int bi = h == 1 ? u : (int)__umulhi((uint32_t)u, inv_h), y = u - bi * h;
+            const uint8_t* p = src + lds_desc[2 * bi] + (size_t)y * src_stride;
+            lds_u32* sq = reinterpret_cast<lds_u32*>(slices + bi * slice_bytes + y * w);
+#pragma unroll
+            for (int x = 0; x < W4; x++) sq[x] = reinterpret_cast<const unaligned_u32*>(p + 4 * x)->v;
         }
     }
     __syncthreads();
@@ -205,14 +222,14 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
     const int ipb = ng * sh, total = nb * ipb;
     const uint32_t inv_ipb = (uint32_t)((0x100000000ull + (uint32_t)ipb - 1u) / (uint32_t)ipb);
     const uint32_t inv_ng = (uint32_t)((0x100000000ull + (uint32_t)ng - 1u) / (uint32_t)ng);
-    const int rstep = (k * pitch) >> 2;
+    const int rstep = k * pitch;  // bytes between the window rows of two block rows
     for (int t = tid; t < total; t += 256) {
         // t / ipb and it / ng by reciprocal (exact below 2^16; a divisor of 1 has no 32-bit reciprocal)
         const int bi = ipb == 1 ? t : (int)__umulhi((uint32_t)t, inv_ipb), it = t - bi * ipb;
-        const int ys = ng == 1 ? it : (int)__umulhi((uint32_t)it, inv_ng), x0 = PPL * (it - ys * ng);
+        const int ys = ng == 1 ? it : (int)__umulhi((uint32_t)it, inv_ng), xg = it - ys * ng, x0 = PPL * xg;
         const lds_u8* blk = slices + bi * slice_bytes;
-        const lds_u32* sp = reinterpret_cast<const lds_u32*>(blk);
-        const lds_u32* wp = reinterpret_cast<const lds_u32*>(blk + blk_bytes + ys * pitch + x0);
+        const lds_u8* sp = blk;
+        const lds_u8* wp = blk + blk_bytes + ys * pitch + x0;
         uint32_t sum[PPL];
 #pragma unroll
         for (int i = 0; i < PPL; i++) sum[i] = 0;
@@ -223,13 +240,37 @@ __global__ void __launch_bounds__(256) sad_loop_qsad_kernel(const uint8_t* __res
             const int y1 = min(h, y0 + FL);
 #pragma unroll 2
             for (int y = y0; y < y1; y++) {
-                const lds_u32* srow = sp + y * W4;
-                const lds_u32* rrow = wp + y * rstep;
-                uint32_t Wd[NW], S[W4];
+                const lds_u8* rrow = wp + y * rstep;
+                uint32_t Wd[4 * CH + 4], S[W4];
+                if constexpr (NQ == 4) {  // x0 and the pitch are multiples of 16
 #pragma unroll
-                for (int j = 0; j < NW; j++) Wd[j] = rrow[j];
+                    for (int c = 0; c < CH; c++) {
+                        const u32x4 v = reinterpret_cast<const lds_u32x4*>(rrow)[c];
+                        Wd[4 * c] = v.x; Wd[4 * c + 1] = v.y; Wd[4 * c + 2] = v.z; Wd[4 * c + 3] = v.w;
+                    }
+                } else if constexpr (NQ == 2) {  // x0 and the pitch are multiples of 8
 #pragma unroll
-                for (int j = 0; j < W4; j++) S[j] = srow[j];
+                    for (int c = 0; c < (NW + 1) / 2; c++) {
+                        const u32x2 v = reinterpret_cast<const lds_u32x2*>(rrow)[c];
+                        Wd[2 * c] = v.x; Wd[2 * c + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NW; j++) Wd[j] = reinterpret_cast<const lds_u32*>(rrow)[j];
+                }
+                const lds_u8* srow = sp + y * w;  // 4 * W4 bytes per block row, the block 16-byte aligned
+                if constexpr (W4 >= 4) {
+#pragma unroll
+                    for (int c = 0; c < W4 / 4; c++) {
+                        const u32x4 v = reinterpret_cast<const lds_u32x4*>(srow)[c];
+                        S[4 * c] = v.x; S[4 * c + 1] = v.y; S[4 * c + 2] = v.z; S[4 * c + 3] = v.w;
+                    }
+                } else if constexpr (W4 == 2) {
+                    const u32x2 v = *reinterpret_cast<const lds_u32x2*>(srow);
+                    S[0] = v.x; S[1] = v.y;
+                } else {
+                    S[0] = *reinterpret_cast<const lds_u32*>(srow);
+                }
 #pragma unroll
                 for (int j = 0; j < W4; j++)
 #pragma unroll
