@@ -44,6 +44,13 @@ __device__ __forceinline__ uint32_t track4(uint32_t best, uint64_t acc, const ui
     return best;
 }
 
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 #pragma unroll
@@ -304,10 +311,23 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
             uint32_t k32x8[2] = {0xffffffffu, 0xffffffffu}, k8x32[2] = {0xffffffffu, 0xffffffffu};
             // One position quad at a time, with a scheduling fence after each: left to itself the scheduler forms the ~200 keys of a 16x16
             // block's 13 trackers all at once for the sake of instruction-level parallelism and spills the live 16x16 sums to make room.
+            if constexpr (FAST) {
+                // 8x8 PUs per position CLASS, as in the 85-PU kernel (me_fullpel_impl.h): packed 16-bit minima over the lane's four quads,
+                // one quad of keys (sad << 16 | class) per PU; the winner's position inside its item is resolved after the search
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t mlo = pk_min_u16(pk_min_u16((uint32_t)acc[k][0], (uint32_t)acc[k][1]), pk_min_u16((uint32_t)acc[k][2], (uint32_t)acc[k][3]));
+                    const uint32_t mhi = pk_min_u16(pk_min_u16((uint32_t)(acc[k][0] >> 32), (uint32_t)(acc[k][1] >> 32)),
+                                                    pk_min_u16((uint32_t)(acc[k][2] >> 32), (uint32_t)(acc[k][3] >> 32)));
+                    k8[k] = track4(k8[k], pack64(mlo, mhi), &idx[0], himask);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                if constexpr (!FAST) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
+                    for (int k = 0; k < 4; k++) k8[k] = track4(k8[k], acc[k][q], &idx[4 * q], himask);
+                }
                 // 16x8 (top / bottom halves) and 8x16 (left / right halves) of this 16x16: packed sums of two 8x8 (<= 16320);
                 // 16x16 = top + bottom (packed u16, no carry between halves: <= 4 * 8160)
                 const uint64_t top = pack64((uint32_t)acc[0][q] + (uint32_t)acc[1][q], (uint32_t)(acc[0][q] >> 32) + (uint32_t)(acc[1][q] >> 32));
@@ -542,7 +562,36 @@ __device__ __forceinline__ void fullpel209_sb(const uint8_t* __restrict__ src_pl
     if (lane == 0) atomicMin(best64_lds, k64);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the ds_min_u32 above are invisible to the compiler's counter tracking
     __syncthreads();
-    if (tid < 209) {
+    if constexpr (FAST) {
+        // resolve the 8x8 winners (key = sad << 16 | y * 128 + 16 * xg + class): lane = 4 * PU + quad recomputes the SADs of positions
+        // 4 quad .. 4 quad + 3 of the winning item; the first position whose SAD equals the minimum is the reference's strict-'<' winner
+        const int p = lane >> 2, q = lane & 3;
+        const int zz = p >> 2, k = p & 3, px = 16 * (zz & 1) + 8 * (k & 1), py = 16 * (zz >> 1) + 8 * (k >> 1);
+        const uint32_t key = pu_key[16 * (4 * Q + zz) + k];
+        const uint32_t s = key >> 16, id = key & 0xffffu;
+        const int y = (int)(id >> 7), xb = (int)(id & 0x70u);
+        const uint8_t* wp = win + (y + 32 * Qy + py) * kPitch + xb + 4 * q + 32 * Qx + px;
+        const uint32_t* sp = src4 + (size_t)py * sstride4 + (px >> 2);
+        uint64_t a = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(wp + 2 * r * kPitch);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            a = __builtin_amdgcn_qsad_pk_u16_u8(pack64(w0, w1), sp[(size_t)(2 * r) * sstride4], a);
+            a = __builtin_amdgcn_qsad_pk_u16_u8(pack64(w1, w2), sp[(size_t)(2 * r) * sstride4 + 1], a);
+        }
+        const uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+        uint32_t first = (lo & 0xffffu) == s ? 0u : (lo >> 16) == s ? 1u : (hi & 0xffffu) == s ? 2u : (hi >> 16) == s ? 3u : 64u;
+        first += 4u * (uint32_t)q;
+        first = min(first, (uint32_t)__shfl_xor((int)first, 1));
+        first = min(first, (uint32_t)__shfl_xor((int)first, 2));
+        if (q == 0) {
+            const int pu = 21 + 16 * Q + p;
+            osad[pu] = 2u * s;
+            omv[pu] = mv_word(xo + xb + (int)first, yo + y);
+        }
+    }
+    if (tid < 209 && !(FAST && tid >= 21 && tid < 85)) {
         const int pu = tid;
         uint32_t raw, id;
         if (pu == 0) {

@@ -502,7 +502,7 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
                 per_cu = 2;
             return (uint32_t)(cus * per_cu);
         }();
-        if (blocks > resident) blocks = resident;
+        if (blocks > 2 * resident) blocks = resident;  // up to two rounds of workgroups there is nothing to walk
     }
     if (lds > 64 * 1024) {
         static hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, false>),
