@@ -62,7 +62,11 @@ int32_t svthip_reserve(svthip_ctx *ctx, uint32_t width, uint32_t height, uint32_
  * two against each other.  Nothing is read from the environment. */
 #define SVTHIP_OPT_SADLOOP_GENERIC 0 /* svthip_sad_loop_batch_dev: one-position-per-lane kernel for every width */
 #define SVTHIP_OPT_CONVOLVE_VALU 1   /* svthip_av1_convolve_*_batch_dev: vector-unit kernel also for sides that are multiples of 32 */
-#define SVTHIP_OPT_COUNT 2
+#define SVTHIP_OPT_TQ_MAX_WORKGROUPS 2 /* svthip_encode_tu[16]_batch_dev: upper bound on the workgroups of a launch (0 = none).  The kernels walk
+                                        * their transform units with whatever grid they get (a large batch already runs on as many workgroups
+                                        * as the chip holds, each wave walking several groups with its operands prefetched one group ahead);
+                                        * a small bound makes a small batch take that path, which is how the tests cover it */
+#define SVTHIP_OPT_COUNT 3
 int32_t svthip_set_option(svthip_ctx *ctx, int32_t option, int32_t value);
 
 /* ---------------------------------------------------------------------------------------------

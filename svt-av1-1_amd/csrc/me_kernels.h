@@ -95,7 +95,7 @@ hipError_t launch_inv_txfm2d_add(const int32_t* coeff, const svthip_itxfm_desc* 
 
 hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int planes_16bit, const svthip_tu_desc* desc, uint32_t n_tu,
                             int w, int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff,
-                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s);
+                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, uint32_t max_workgroups, hipStream_t s);
 
 __global__ void fullpel209_kernel(const uint8_t* __restrict__ src_plane, uint32_t src_stride, const uint8_t* __restrict__ ref_plane,
                                   uint32_t ref_stride, const int32_t* __restrict__ desc, uint32_t n_sb, uint32_t* __restrict__ out_sad,

@@ -511,7 +511,8 @@ static int32_t encode_tu_common(svthip_ctx* ctx, const void* d_src, const void* 
         return fail(SVTHIP_ERR_BAD_PARAMETER, "16-bit planes must be 2-byte aligned%s", "");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qparams, d_iscan,
-                                     d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_three_quad_energy, d_distortion, s));
+                                     d_coeff, d_qcoeff, d_dqcoeff, d_eob, d_three_quad_energy, d_distortion,
+                                     (uint32_t)ctx->opt[SVTHIP_OPT_TQ_MAX_WORKGROUPS], s));
     return SVTHIP_OK;
 }
 
@@ -1126,7 +1127,7 @@ int32_t svthip_encode_tu_batch(svthip_ctx* ctx, const void* src, const void* pre
         HIP_TRY(hipMemcpyAsync(d_q, qcoeff, cb, hipMemcpyHostToDevice, s));
         if (dqcoeff) HIP_TRY(hipMemcpyAsync(d_dq, dqcoeff, cb, hipMemcpyHostToDevice, s));
         HIP_TRY(svthip::launch_encode_tu(d_src, d_pred, d_recon, planes_16bit ? 1 : 0, d_desc, n_tu, (int)tx_width, (int)tx_height, d_qp, d_iscan, d_coeff,
-                                         d_q, d_dq, d_eob, d_en, d_dist, s));
+                                         d_q, d_dq, d_eob, d_en, d_dist, (uint32_t)ctx->opt[SVTHIP_OPT_TQ_MAX_WORKGROUPS], s));
         HIP_TRY(hipMemcpyAsync(recon, d_recon, pb, hipMemcpyDeviceToHost, s));
         if (coeff) HIP_TRY(hipMemcpyAsync(coeff, d_coeff, cb, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(qcoeff, d_q, cb, hipMemcpyDeviceToHost, s));

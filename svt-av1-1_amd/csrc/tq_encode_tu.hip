@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
 template <int WL, int HL, typename PIX>
 hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_tu_desc* desc, uint32_t n_tu,
                       const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
-                      uint64_t* energy, uint64_t* dist, hipStream_t s)
+                      uint64_t* energy, uint64_t* dist, uint32_t max_wg, hipStream_t s)
 {
     constexpr int W = 1 << WL, H = 1 << HL, MIND = W < H ? W : H, G = 64 / MIND;
     constexpr bool QSTAGE = (W == H) && W <= 32;  // as in the kernel
@@ -504,6 +504,7 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
         }();
         if (blocks > 2 * resident) blocks = resident;  // up to two rounds of workgroups there is nothing to walk
     }
+    if (max_wg && blocks > max_wg) blocks = max_wg;  // SVTHIP_OPT_TQ_MAX_WORKGROUPS (every kernel form walks its groups grid-stride)
     if (lds > 64 * 1024) {
         static hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_tu_kernel<WL, HL, PIX, false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -524,12 +525,12 @@ hipError_t launch_one(const PIX* src, const PIX* pred, PIX* recon, const svthip_
 template <typename PIX>
 hipError_t launch_sized(const PIX* src, const PIX* pred, PIX* recon, const svthip_tu_desc* desc, uint32_t n_tu, int w, int h,
                         const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff, int32_t* dqcoeff, uint16_t* eob,
-                        uint64_t* energy, uint64_t* dist, hipStream_t s)
+                        uint64_t* energy, uint64_t* dist, uint32_t max_wg, hipStream_t s)
 {
     const int key = clog2(w) * 8 + clog2(h);
 #define CASE(WL, HL) \
     case (WL) * 8 + (HL): \
-        return launch_one<WL, HL, PIX>(src, pred, recon, desc, n_tu, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s)
+        return launch_one<WL, HL, PIX>(src, pred, recon, desc, n_tu, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, max_wg, s)
     switch (key) {
         CASE(2, 2); CASE(3, 3); CASE(4, 4); CASE(5, 5); CASE(6, 6);
         CASE(2, 3); CASE(3, 2); CASE(3, 4); CASE(4, 3); CASE(4, 5); CASE(5, 4); CASE(5, 6); CASE(6, 5);
@@ -543,13 +544,13 @@ hipError_t launch_sized(const PIX* src, const PIX* pred, PIX* recon, const svthi
 
 hipError_t launch_encode_tu(const void* src, const void* pred, void* recon, int planes_16bit, const svthip_tu_desc* desc, uint32_t n_tu,
                             int w, int h, const int16_t* qparams, const int16_t* iscan, int32_t* coeff, int32_t* qcoeff,
-                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, hipStream_t s)
+                            int32_t* dqcoeff, uint16_t* eob, uint64_t* energy, uint64_t* dist, uint32_t max_workgroups, hipStream_t s)
 {
     if (planes_16bit)
         return launch_sized<uint16_t>(static_cast<const uint16_t*>(src), static_cast<const uint16_t*>(pred), static_cast<uint16_t*>(recon),
-                                      desc, n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s);
+                                      desc, n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, max_workgroups, s);
     return launch_sized<uint8_t>(static_cast<const uint8_t*>(src), static_cast<const uint8_t*>(pred), static_cast<uint8_t*>(recon), desc,
-                                 n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, s);
+                                 n_tu, w, h, qparams, iscan, coeff, qcoeff, dqcoeff, eob, energy, dist, max_workgroups, s);
 }
 
 }  // namespace svthip

@@ -161,6 +161,7 @@ def lib() -> C.CDLL:
 
 OPT_SADLOOP_GENERIC = 0
 OPT_CONVOLVE_VALU = 1
+OPT_TQ_MAX_WORKGROUPS = 2
 
 
 class SvtHipError(RuntimeError):
@@ -198,7 +199,7 @@ class Context:
         _check(lib().svthip_synchronize(self._h))
 
     def set_option(self, option: int, value: int):
-        """svthip_set_option: kernel-selection override of this context (OPT_SADLOOP_GENERIC / OPT_CONVOLVE_VALU)."""
+        """svthip_set_option: kernel-selection override of this context (OPT_SADLOOP_GENERIC / OPT_CONVOLVE_VALU / OPT_TQ_MAX_WORKGROUPS)."""
         _check(lib().svthip_set_option(self._h, option, value))
 
     def reserve(self, width: int, height: int, n_pu: int = 85, n_jobs: int = 1, host_forms: bool = False):

@@ -199,3 +199,34 @@ def test_encode_tu16_batch_matches_oracle(hip_ctx, oracle, size):
     assert np.array_equal(d_en.cpu().numpy().view(np.uint64), ref["energy"])
     assert np.array_equal(d_dist.cpu().numpy().view(np.uint64), ref["dist"])
     assert np.array_equal(d_pred.cpu().numpy().view(np.uint16), ref["recon"])
+
+
+@pytest.mark.parametrize("case", [(4, 4, 8, 3001), (8, 8, 8, 1501), (16, 16, 8, 1203), (32, 32, 8, 331), (64, 64, 8, 37), (16, 8, 8, 403), (32, 64, 8, 45),
+                                  (4, 4, 10, 1999), (16, 16, 10, 801), (32, 32, 10, 203), (64, 64, 10, 21)])
+@pytest.mark.parametrize("max_wg", [1, 3])
+def test_encode_tu_many_groups_per_wave(hip_ctx, oracle, case, max_wg):
+    """The path a large batch takes -- few workgroups, every wave walking MANY groups of TUs with the next group's descriptor and rows
+    prefetched and the reconstruction store deferred by one group -- on a small batch (SVTHIP_OPT_TQ_MAX_WORKGROUPS), in place, with a TU
+    count that is not a multiple of the TUs per wave: quantised coefficients, end of block and reconstruction against the oracle."""
+    torch = pytest.importorskip("torch")
+    w, h, bd, n_tu = case
+    rng = np.random.default_rng(w * 1000 + h * 10 + bd + max_wg)
+    pic_w = 1024
+    pic_h = ((n_tu + pic_w // w - 1) // (pic_w // w) + 2) * h
+    b = random_encode_batch(rng, n_tu, w, h, pic_w=pic_w, pic_h=pic_h, bit_depth=bd)
+    ref = oracle_encode_batch(oracle, b)
+    n = b["n"]
+    d_src, d_pred, d_desc, d_qp, d_iscan = _dev(b["src"]), _dev(b["pred"]), _dev(b["desc"]), _dev(b["qparams"]), _dev(b["iscan"])
+    d_q = torch.full((n_tu * n,), 5, dtype=torch.int32, device="cuda:0")
+    d_eob = torch.full((n_tu,), -1, dtype=torch.int16, device="cuda:0")
+    hip_ctx.set_option(svtav1_hip.OPT_TQ_MAX_WORKGROUPS, max_wg)
+    try:
+        hip_ctx.encode_tu_batch_dev(d_src.data_ptr(), d_pred.data_ptr(), d_pred.data_ptr(), d_desc.data_ptr(), n_tu, w, h, d_qp.data_ptr(),
+                                    d_iscan.data_ptr(), None, d_q.data_ptr(), None, d_eob.data_ptr(), None, None, planes_16bit=(bd == 10))
+        hip_ctx.synchronize()
+    finally:
+        hip_ctx.set_option(svtav1_hip.OPT_TQ_MAX_WORKGROUPS, 0)
+    assert np.array_equal(d_q.cpu().numpy(), ref["qcoeff"])
+    assert np.array_equal(d_eob.cpu().numpy().view(np.uint16), ref["eob"])
+    got = d_pred.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16) if bd == 10 else got, ref["recon"])
