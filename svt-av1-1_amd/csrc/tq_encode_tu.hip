@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
     // QSTAGE (square sizes up to 32): the quantised coefficients leave through a per-wave LDS image [64 rows][W + 4] and are stored as
     // contiguous 1 KB pieces per instruction.  Stored straight from the row lanes, every lane's 16 bytes were their own write request at the L2
     // (64 per instruction, 256 per group of 1024 pixels), and the stamps showed the row pass -- the one that issues them -- taking half of a
-    // group's time with a 4x spread (profiles/r03_tq_stamps_16x16_before.txt): waves queueing at the vector-memory issue.
+    // group's time with a 4x spread (an earlier run of tools/tq_stamps_probe.py; profiles/r03_tq_stamps_16x16.txt is the current build): waves queueing at the vector-memory issue.
     constexpr bool QSTAGE = (W == H) && W <= 32;
     constexpr int QP_ = W + 4;                                  // staging row pitch in dwords: 16-byte rows at a stride that spreads the banks
     constexpr int WAVE_LDS = G * H * P + (QSTAGE ? 64 * QP_ + 16 : 0);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Phase time stamps of the fused T/Q chain (square size n, 64 M-pixel plane), from a build with -DSVTHIP_TQ_STAMPS
 (tools/build_variant.sh stamps csrc/tq_encode_tu.hip -DSVTHIP_TQ_STAMPS; SVTAV1_HIP_LIB=.../variants/libsvtav1_hip_stamps.so).
-Per group of a wave: top (operands of the group taken over, next descriptor requested) | A0 | A | next rows requested | B | C | D.
+Per group of a wave: top (operands of the group taken over, next descriptor requested) + A0 | A | next rows requested | B (forward row, quantiser,
+inverse row) | staged coefficient stores + C | D.
 usage: python tools/tq_stamps_probe.py [n]"""
 import os
 import sys
@@ -44,10 +45,10 @@ st = d_c.cpu().numpy().view(np.uint64)[:groups * 8].reshape(groups, 8)
 ok = st[:, 0] > 0
 st = st[ok]
 print(f"{n}x{n}: {groups} groups, {ok.sum()} stamped; kernel span {(st[:, 6].max() - st[:, 0].min())} ticks")
-names = ["top", "A0", "A", "prefetch", "B", "C", "D"]
+names = ["top + A0", "A", "prefetch", "B", "flush + C", "D"]
 dt = np.diff(st[:, :7].astype(np.int64), axis=1)
 for k in range(6):
-    print(f"  {names[k]:9s} mean {dt[:, k].mean():9.0f}  p10 {np.percentile(dt[:, k], 10):9.0f}  p50 {np.percentile(dt[:, k], 50):9.0f}  p90 {np.percentile(dt[:, k], 90):9.0f}")
+    print(f"  {names[k]:10s} mean {dt[:, k].mean():9.0f}  p10 {np.percentile(dt[:, k], 10):9.0f}  p50 {np.percentile(dt[:, k], 50):9.0f}  p90 {np.percentile(dt[:, k], 90):9.0f}")
 tot = (st[:, 6] - st[:, 0]).astype(np.int64)
 print(f"  group     mean {tot.mean():9.0f}  p10 {np.percentile(tot, 10):9.0f}  p50 {np.percentile(tot, 50):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
 wid = st[:, 7]
