@@ -122,8 +122,13 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
     unaligned_row<5> qp_nx{};                // ... the ten int16 quantiser parameters,
     short4 isc_nx[HOIST_ISCAN ? W / 4 : 1];  // ... inverse-scan row
     auto fetch_rows = [&](const svthip_tu_desc& d) {
+#ifdef SVTHIP_TQ_EXP_NOMEM  // timing experiment (tools/build_variant.sh): no plane traffic, results meaningless
+#pragma unroll
+        for (int c = 0; c < ROWDW; c++) { sv_nx.v[c] = d.src_offset * 0x9e3779b1u + (uint32_t)(lane * 131 + c); pv_nx.v[c] = sv_nx.v[c] ^ 0x01030507u; }
+#else
         sv_nx = *reinterpret_cast<const unaligned_row<ROWDW>*>(src + d.src_offset + (size_t)hi * d.src_stride);
         pv_nx = *reinterpret_cast<const unaligned_row<ROWDW>*>(pred + d.pred_offset + (size_t)hi * d.pred_stride);
+#endif
         qp_nx = *reinterpret_cast<const unaligned_row<5>*>(qparams + (size_t)d.qparam_index * 10);
         if constexpr (HOIST_ISCAN) {
             const int16_t* iscan = iscan_pool + d.iscan_offset + hi * WIN;
@@ -197,7 +202,9 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
             for (int c = 0; c < (HOIST_ISCAN ? W / 4 : 1); c++) isc[c] = isc_nx[c];
             if constexpr (PIPE) {
                 rd_nx = load_desc_raw(min((grp + gstride) * G + g, n_tu - 1));
+#ifndef SVTHIP_TQ_EXP_NOMEM
                 if (o_ptr) *reinterpret_cast<unaligned_row<ROWDW>*>(o_ptr) = o_dfr;
+#endif
                 o_ptr = nullptr;
             }
             if (tu < n_tu) {
@@ -389,7 +396,12 @@ __global__ void __launch_bounds__(256, (WL >= 6 || HL >= 6) ? 2 : 1) encode_tu_k
                 const int q = k * 64 + lane, R = q / (W / 4), cq = q % (W / 4);
                 const int4 v = *reinterpret_cast<const int4*>(qst + R * QP_ + 4 * cq);
                 const uint32_t off = (uint32_t)qst[64 * QP_ + R / H];
-                if (off != 0xffffffffu) *reinterpret_cast<int4*>(qcoeff_out + off + (R % H) * W + 4 * cq) = v;
+#ifdef SVTHIP_TQ_EXP_NOMEM
+                if (off == 0xfffffff0u)
+#else
+                if (off != 0xffffffffu)
+#endif
+                    *reinterpret_cast<int4*>(qcoeff_out + off + (R % H) * W + 4 * cq) = v;
             }
         }
         SVTHIP_STAMP(4);
