@@ -37,20 +37,49 @@ constexpr int kSadStride = 36;           // SAD table [85][36]
 constexpr int kScr = 112;                // projected main array of one sub-item: m[k] at byte 36 + k, k = -32 .. 65
 constexpr int kCand = 18;                // MAX_OPEN_LOOP_INTRA_CANDIDATES
 
-__device__ const int8_t kOisAngle[17] = {-32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};  // modes 18..34
-__device__ const uint16_t kOisInv[8] = {256, 315, 390, 482, 630, 910, 1638, 4096};                             // modes 18..25
-__device__ const uint8_t kOisModeList[4][36] = {
+__constant__ const uint8_t kOisModeList[4][36] = {
     {7, 0, 1, 10, 26, 2, 18, 34},                   // I pictures: PL, DC, H, V, 2, 18, 34
     {35, 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
      18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34},
     {1, 1},                                         // limit_ois_to_dc_mode_flag
     {10, 1, 10, 26, 2, 18, 34, 6, 14, 22, 30}};     // DC + stage1ModesArray
-__device__ const int16_t kOisPointTh[3][6][4] = {
+// What a mode-loop iteration needs, ONE dword per (mode list, entry) in the constant address space: mode | angle of its vertical twin << 8 |
+// inverse angle << 16; entry 0 = the number of modes.  The index is wave-uniform, so the look-up is a scalar load.  As three byte / halfword
+// tables (mode list, angle, inverse angle) every iteration issued three dependent vector loads -- 280 per wave, the texture path busy 0.7 of
+// the launch and the waves waiting 57 % of their time (profiles/r03_pmcx_ois_before.txt).
+struct OisModeInfo {
+    uint32_t v[4][36];
+};
+constexpr OisModeInfo ois_make_mode_info()
+{
+    constexpr int8_t angle_of[17] = {-32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
+    constexpr uint16_t inv_of[8] = {256, 315, 390, 482, 630, 910, 1638, 4096};
+    constexpr uint8_t lists[4][36] = {{7, 0, 1, 10, 26, 2, 18, 34},
+                                      {35, 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                                       18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34},
+                                      {1, 1},
+                                      {10, 1, 10, 26, 2, 18, 34, 6, 14, 22, 30}};
+    OisModeInfo t{};
+    for (int p = 0; p < 4; p++) {
+        t.v[p][0] = lists[p][0];
+        for (int i = 1; i <= lists[p][0]; i++) {
+            const int m = lists[p][i];
+            const bool frame_v = m >= 18 || m < 2;
+            const int vm = m < 2 ? m : frame_v ? m : 36 - m;
+            const int angle = vm >= 18 ? angle_of[vm - 18] : 0;
+            const uint32_t inv = (vm >= 18 && angle < 0) ? inv_of[vm - 18] : 0u;
+            t.v[p][i] = (uint32_t)m | ((uint32_t)(uint8_t)(int8_t)angle << 8) | (inv << 16);
+        }
+    }
+    return t;
+}
+__constant__ const OisModeInfo kOisModeInfo = ois_make_mode_info();
+__constant__ const int16_t kOisPointTh[3][6][4] = {
     {{-20, 50, 150, 200}, {-20, 50, 150, 200}, {-20, 50, 100, 150}, {-20, 50, 200, 300}, {-20, 50, 200, 300}, {-20, 50, 200, 300}},
     {{-150, 0, 150, 200}, {-150, 0, 150, 200}, {-125, 0, 100, 150}, {-50, 50, 200, 300}, {-50, 50, 200, 300}, {-50, 50, 200, 300}},
     {{-400, -300, -200, 0}, {-400, -300, -200, 0}, {-400, -300, -200, 0}, {-400, -300, -200, 0}, {-400, -300, -200, 0}, {-400, -300, -200, 0}}};
 // InjectIntraCandidatesBasedOnBestMode (:7525-7776): the nine modes written for each stage-1 winner, in stage1ModesArray order
-__device__ const uint8_t kOisInject[9][9] = {
+__constant__ const uint8_t kOisInject[9][9] = {
     {10, 1, 0, 9, 11, 8, 12, 7, 13},    {26, 1, 0, 25, 27, 24, 28, 23, 29}, {2, 1, 0, 3, 4, 5, 7, 8, 9},
     {18, 1, 0, 17, 19, 16, 20, 15, 21}, {34, 1, 0, 33, 32, 29, 31, 27, 28}, {6, 1, 0, 7, 5, 4, 8, 3, 9},
     {14, 1, 0, 13, 15, 12, 16, 11, 17}, {22, 1, 0, 21, 23, 20, 24, 19, 25}, {30, 1, 0, 29, 31, 28, 32, 27, 33}};
@@ -99,7 +128,7 @@ __device__ __forceinline__ uint32_t sub_sum(uint32_t v)  // sum over the LPS con
 // SADs of the modes in `list` for the CUs first_cu .. first_cu + NSUB - 1 (S x S each), one wave.
 //   S = 8 : 4 CUs per pass (16 lanes each);  S = 16 : one CU per pass;  S = 32 : one CU in four passes of 8 rows.
 template <int S>
-__device__ __forceinline__ void ois_unit(OisLds& L, int first_cu, int level_first, const uint8_t* list, uint8_t* scr_wave)
+__device__ __forceinline__ void ois_unit(OisLds& L, int first_cu, int level_first, const uint32_t* list, uint8_t* scr_wave)
 {
     constexpr int LPS = (S == 8) ? 16 : 64;        // lanes per CU
     constexpr int IT = (S == 32) ? 4 : 1;          // passes per mode
@@ -142,9 +171,10 @@ __device__ __forceinline__ void ois_unit(OisLds& L, int first_cu, int level_firs
         dc = ((uint32_t)__shfl((int)v, sub * LPS) + S) >> (LG + 1);
     }
 
-    const int n_modes = list[0];
+    const int n_modes = (int)list[0];
     for (int mi = 0; mi < n_modes; mi++) {
-        const int mode = list[1 + mi];  // wave-uniform
+        const uint32_t info = list[1 + mi];  // wave-uniform: a scalar load
+        const int mode = (int)(info & 0xffu);
         const bool frame_v = (mode >= 18) || (mode < 2);
         const uint8_t* A = frame_v ? L.T : L.TT;
         const uint8_t* B = frame_v ? L.TT : L.T;
@@ -153,11 +183,11 @@ __device__ __forceinline__ void ois_unit(OisLds& L, int first_cu, int level_firs
         const int vm = (mode < 2) ? mode : (frame_v ? mode : 36 - mode);
         uint32_t acc = 0;
         if (vm >= 18) {
-            const int angle = kOisAngle[vm - 18];
+            const int angle = (int)(int8_t)(info >> 8);
             const uint8_t* mp = A;
             int mo = mb;
             if (angle < 0) {
-                const int inv = kOisInv[vm - 18];
+                const int inv = (int)(info >> 16);
                 for (int t = l; t <= 2 * S; t += LPS) {
                     const int k = t - S;
                     uint8_t v;
@@ -354,7 +384,7 @@ __global__ void __launch_bounds__(256) ois_kernel(const uint8_t* __restrict__ po
     __syncthreads();
 
     const int path = P.slice_is_intra ? 0 : (P.temporal_layer_index == 0 && !P.input_resolution_4k) ? 1 : P.limit_ois_to_dc_mode_flag ? 2 : 3;
-    const uint8_t* list = kOisModeList[path];
+    const uint32_t* list = kOisModeInfo.v[path];
     const int wave = tid >> 6;
     uint8_t* scr_wave = L.scr + wave * 4 * kScr;
     // per wave: one 32x32 CU, four 16x16 CUs, four groups of four 8x8 CUs (48 equal pass-units per SB and mode)
