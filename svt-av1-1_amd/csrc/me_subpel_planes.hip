@@ -152,6 +152,8 @@ struct Ctx {
     Planes P;
     int xo, yo;
     uint32_t *sad_io, *mv_io;  // this SB's [n_pu] arrays
+    const lds_u32* in_tab;     // LDS copy of what a PU's refinement starts from: [0,209) PU table (ME-buffer index | px << 8 | py << 16 in class
+                               // order), [256, 256 + n_pu) full-pel SADs, [512, 512 + n_pu) full-pel vectors (ME-buffer order)
     uint32_t* pred;            // this SB's prediction slots ([slots][1024 dwords], slots in the class order above), or null
     lds_u32* shake;            // hand-shake area of the 64x64 PU (two waves): 17 half-pel sums, 6 quarter-pel sums, 2 arrival counters
     int lane;
@@ -182,9 +184,11 @@ __device__ void refine_class_half(const Ctx& c, int half, bool refine, int u_fir
         const int pu_in_class = CPP >= 4 ? chunk / CQ : chunk * UNITS + u;
         const int cell0 = CPP >= 4 ? (chunk % CQ) * 4 : 0;
         const int cx0 = cell0 % CW, cy0 = cell0 / CW;
-        const uint32_t ppk = kPuPacked.v[kClass[CLS].base + pu_in_class];
+        // from LDS (staged by the workgroup before the plane phases): as a table look-up in memory followed by two loads that depend on it,
+        // every unit of every wave began with two dependent memory round trips
+        const uint32_t ppk = c.in_tab[kClass[CLS].base + pu_in_class];
         const int me = (int)(ppk & 255u), px = (int)((ppk >> 8) & 255u), py = (int)(ppk >> 16);
-        uint32_t best_sad = c.sad_io[me], best_mv = c.mv_io[me], best_ssd = 0;
+        uint32_t best_sad = c.in_tab[256 + me], best_mv = c.in_tab[512 + me], best_ssd = 0;
         const uint8_t* srow = c.src + (size_t)(py + 8 * cy0 + r) * c.src_stride + px + 8 * cx0;  // row r of the chunk's first cell
         const size_t s8 = 8 * (size_t)c.src_stride;
         if (refine) {
@@ -481,6 +485,13 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     lds_u8* const PB = P.A + P.D;
     lds_u8* const PH = PB + P.D;
     lds_u8* const PJ = PH + P.D;
+    // behind the planes (and their 32 bytes of read slack): the PUs' starting values, visible after the barriers of the plane phases
+    lds_u32* const in_tab = (lds_u32*)(PJ + P.D + 32);
+    for (int i = tid; i < 209; i += nthr) in_tab[i] = kPuPacked.v[i];
+    for (int i = tid; i < n_pu; i += nthr) {
+        in_tab[256 + i] = sad_io[i];
+        in_tab[512 + i] = mv_io[i];
+    }
 
     // The plane phases are a chain of short, dependent steps (vectors -> box -> window -> b, h -> j, four barriers) that the whole workgroup
     // waits for, while the PU phase of the CU's other workgroup is a long stream of independent vector work: run the chain at raised wave
@@ -611,6 +622,7 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.yo = yo;
     c.sad_io = sad_io;
     c.mv_io = mv_io;
+    c.in_tab = in_tab;
     c.pred = pred_out ? pred_out + (size_t)sb * (n_pu == 209 ? 14 : 4) * 1024 : nullptr;
     c.shake = ctl + 4;
     c.lane = lane;
@@ -674,7 +686,7 @@ uint32_t subpel_planes_grid(uint32_t n_sb)
 size_t subpel_planes_lds_bytes(uint32_t max_sw, uint32_t max_sh)
 {
     const size_t pitch = subpel_plane_pitch((int)max_sw + 69), rows = max_sh + 69;
-    return 128 + 4 * ((pitch * rows + 15) & ~(size_t)15) + 32;  // + slack: the 3-dword reads run up to 11 bytes past a sample
+    return 128 + 4 * ((pitch * rows + 15) & ~(size_t)15) + 32 + 4 * (512 + 209 + 3);  // + slack (the 3-dword reads run up to 11 bytes past a sample) + the PUs' starting values
 }
 
 }  // namespace svthip
