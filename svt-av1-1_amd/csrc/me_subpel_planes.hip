@@ -417,14 +417,15 @@ __device__ __forceinline__ void run_class(const Ctx& c, int half, bool refine, i
 // 23.8 k ticks against 13 - 15 k for the other six, with the workgroup (and its 71 KB of LDS) waiting for them.  So the classes with 4 / 2
 // PUs per chunk (8x8; 16x8, 8x16) are cut into per-PU slices and dealt out by measured cost.  Entry: class | half << 4 | first << 5 |
 // count << 7, 0xffff ends a wave's list.  The two halves of the 64x64 PU (which hand-shake through the LDS) lead the lists of two waves.
-#define T(cls, half, first, count) (uint16_t)((cls) | ((half) << 4) | ((first) << 5) | ((count) << 7))
-#define TEND (uint16_t)0xffff
-__device__ constexpr uint16_t kTasks85[8][4] = {
+// (dwords in the constant address space: the index is wave-uniform, so a wave's next task is a scalar load, not a vector load + readfirstlane)
+#define T(cls, half, first, count) (uint32_t)((cls) | ((half) << 4) | ((first) << 5) | ((count) << 7))
+#define TEND (uint32_t)0xffff
+__constant__ const uint32_t kTasks85[8][4] = {
     {T(0, 0, 0, 1), TEND, TEND, TEND},          {T(0, 1, 0, 1), TEND, TEND, TEND},
     {T(1, 0, 0, 1), T(3, 0, 0, 1), TEND, TEND}, {T(1, 1, 0, 1), T(3, 1, 0, 1), TEND, TEND},
     {T(2, 0, 0, 1), TEND, TEND, TEND},          {T(2, 1, 0, 1), TEND, TEND, TEND},
     {T(3, 0, 1, 3), TEND, TEND, TEND},          {T(3, 1, 1, 3), TEND, TEND, TEND}};
-__device__ constexpr uint16_t kTasks209[7][6] = {
+__constant__ const uint32_t kTasks209[7][6] = {
     {T(0, 0, 0, 1), T(3, 1, 0, 3), T(7, 0, 0, 1), T(10, 1, 0, 1), TEND, TEND},
     {T(0, 1, 0, 1), T(4, 0, 0, 1), T(7, 1, 0, 1), T(11, 0, 0, 1), T(3, 1, 3, 1), TEND},
     {T(1, 0, 0, 1), T(4, 1, 0, 1), T(8, 0, 0, 1), T(11, 1, 0, 1), T(3, 0, 2, 2), TEND},
@@ -628,7 +629,8 @@ __global__ void __launch_bounds__(512, 4) subpel_planes_kernel(const uint8_t* __
     c.lane = lane;
     c.method = __builtin_amdgcn_readfirstlane(method);
 #ifndef SVTHIP_SUBPEL_EXPERIMENT_NO_PU
-    const uint16_t* tasks = n_pu == 209 ? kTasks209[wave < 7 ? wave : 0] : kTasks85[wave & 7];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t* tasks = n_pu == 209 ? kTasks209[wave_u < 7 ? wave_u : 0] : kTasks85[wave_u & 7];
     const int max_tasks = (n_pu == 209 ? 6 : 4) * ((n_pu == 209 ? wave < 7 : wave < 8) ? 1 : 0);
 #pragma unroll 1
     for (int k = 0; k < max_tasks; k++) {
