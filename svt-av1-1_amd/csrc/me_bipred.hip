@@ -212,6 +212,11 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t bisad[85];  // indexed by ME-buffer PU index
+    // both lists' vectors and the raster -> ME-buffer index tables, staged with the windows: read from memory inside the PU loops, every pass
+    // of the 16x16 / 8x8 waves began with a table look-up and two vector loads that depend on it (the kernel ran at a quarter of its vector
+    // issue rate, waiting)
+    __shared__ uint32_t mv_l[2][85];
+    __shared__ uint8_t tab_l[80];
     const int tid = threadIdx.x, lane = tid & 63;
     // role of this wave: 0 = 64x64, 1 = 32x32s, 2 = 16x16s, 3 = 8x8s.  The roles differ in work (the 8x8 wave fills twice the
     // tile samples of the 64x64 wave) and wave k of every workgroup lands on SIMD k, so the assignment rotates with the
@@ -239,6 +244,12 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             reinterpret_cast<lds_u32*>(src_lds)[i] =
                 *reinterpret_cast<const uint32_t*>(src_plane + d0[0] + (size_t)r * src_stride + 4 * c);
         }
+        if (tid < 85) {
+            mv_l[0][tid] = m0[tid];
+            mv_l[1][tid] = m1[tid];
+            if (tid < 16) tab_l[tid] = kTab16[tid];
+            if (tid < 64) tab_l[16 + tid] = kTab8[tid];
+        }
         stage_window(w0buf, pitch0, d0[5] + 63 + 2 * kMargin, ref0_plane, d0[1], ref0_stride, tid);
         stage_window(w1buf, pitch1, d1[5] + 63 + 2 * kMargin, ref1_plane, d1[1], ref1_stride, tid);
         __syncthreads();
@@ -246,14 +257,14 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
         const int xo0 = d0[2], yo0 = d0[3], xo1 = d1[2], yo1 = d1[3];
         if (wave == 0) {
             Tiles<64> t{tile_base, tile_base + 68 * 72, tile_base + 68 * 72 + 68 * 68};
-            const uint32_t v = bipred_pu<64, 64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, m0[0], xo0, yo0, m1[0], xo1, yo1, lane);
+            const uint32_t v = bipred_pu<64, 64, 64>(src_lds, win0, win1, t, pred_base, 0, 0, mv_l[0][0], xo0, yo0, mv_l[1][0], xo1, yo1, lane);
             if (lane == 0) bisad[0] = v;
         } else if (wave == 1) {
             lds_u8* b = tile_base + t64;
             Tiles<32> t{b, b + 36 * 40, b + 36 * 40 + 36 * 36};
             for (int p = 0; p < 4; p++) {
-                const uint32_t v = bipred_pu<32, 32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, m0[1 + p],
-                                                     xo0, yo0, m1[1 + p], xo1, yo1, lane);
+                const uint32_t v = bipred_pu<32, 32, 64>(src_lds, win0, win1, t, pred_base + 4096, (p & 1) << 5, (p >> 1) << 5, mv_l[0][1 + p],
+                                                     xo0, yo0, mv_l[1][1 + p], xo1, yo1, lane);
                 if (lane == 0) bisad[1 + p] = v;
             }
         } else if (wave == 2) {
@@ -262,9 +273,9 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             Tiles<16> t{b, b + 20 * 24, b + 20 * 24 + 20 * 20};
             for (int pass = 0; pass < 4; pass++) {
                 const int p = pass * 4 + g;
-                const int n = 5 + kTab16[p];
+                const int n = 5 + tab_l[p];
                 const uint32_t v = bipred_pu<16, 16, 16>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + g * 256, (p & 3) << 4, (p >> 2) << 4,
-                                                     m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 15);
+                                                     mv_l[0][n], xo0, yo0, mv_l[1][n], xo1, yo1, lane & 15);
                 if ((lane & 15) == 0) bisad[n] = v;
             }
         } else if (bipred_8x8) {
@@ -273,9 +284,9 @@ __global__ void __launch_bounds__(256) bipred_pack_kernel(const uint8_t* __restr
             Tiles<8> t{b, b + 12 * 16, b + 12 * 16 + 12 * 12};
             for (int pass = 0; pass < 8; pass++) {
                 const int p = pass * 8 + g;
-                const int n = 21 + kTab8[p];
+                const int n = 21 + tab_l[16 + p];
                 const uint32_t v = bipred_pu<8, 8, 8>(src_lds, win0, win1, t, pred_base + 4096 + 1024 + kGroups16 * 256 + g * 64, (p & 7) << 3,
-                                                   (p >> 3) << 3, m0[n], xo0, yo0, m1[n], xo1, yo1, lane & 7);
+                                                   (p >> 3) << 3, mv_l[0][n], xo0, yo0, mv_l[1][n], xo1, yo1, lane & 7);
                 if ((lane & 7) == 0) bisad[n] = v;
             }
         }
